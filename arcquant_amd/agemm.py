@@ -1,0 +1,181 @@
+"""Drop-in mirror of the reference's pybind11 module ``agemm`` (kernels/src/bindings.cpp:551-575).
+
+Same function names, argument names, argument meaning, return shapes/dtypes and error behaviour
+(``RuntimeError`` on an unsupported shape) as the reference, but every call goes through the C-ABI of
+``libarcq_hip.so`` (hand-written gfx950 kernels).  ``torch`` is used only for device memory and the
+current HIP stream.
+
+Differences a caller can observe, all deliberate (DESIGN.md "deviations"):
+  * launches go to torch's CURRENT stream (the reference uses the legacy default stream), so the ops are
+    capturable in HIP graphs and ordered with surrounding torch work without device-wide syncs;
+  * KQ is not limited to the reference's closed template list (bindings.cpp:141-160);
+  * ``matmul(..., scale)`` also accepts a 0-dim device tensor WITHOUT a device->host sync;
+  * ``rmsnorm_quantize_x`` uses the same augmented-K layout as the weights for KQ=3584 (the reference
+    mixes the two layouts there); ``variant=VARIANT_G16`` reproduces the reference byte for byte.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import VARIANT_G16, VARIANT_G32, OUT_BF16, OUT_F32, ArcqError  # noqa: F401  (re-exported)
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _need(t: torch.Tensor, dtype, name: str, ndim=None):
+    # the reference's data_ptr<T>() throws c10::Error on a dtype mismatch; we raise RuntimeError
+    if not isinstance(t, torch.Tensor) or t.dtype != dtype:
+        raise RuntimeError(f"agemm: {name} must be a {dtype} tensor, got {getattr(t, 'dtype', type(t))}")
+    if not t.is_cuda:
+        raise RuntimeError(f"agemm: {name} must live on the GPU (there is no CPU path)")
+    if ndim is not None and t.dim() != ndim:
+        raise RuntimeError(f"agemm: {name} must be {ndim}-D, got shape {tuple(t.shape)}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"agemm: {name} must be contiguous")
+
+
+def variant_for_kq(KQ: int) -> int:
+    """Layout variant the reference's dispatch picks for this in_features (bindings.cpp:141-160)."""
+    return int(_lib.lib().arcq_variant_for_kq(int(KQ)))
+
+
+def sf_buffer_bytes(rows: int, K: int) -> int:
+    """get_sf{a,b}_buffer_size_in_bytes (bindings.cpp:83-95)."""
+    return int(_lib.lib().arcq_sf_alloc_bytes(int(rows), int(K)))
+
+
+def _quantize(fn_name: str, X: torch.Tensor, reorder_index: torch.Tensor, KE: int, variant):
+    _need(X, torch.bfloat16, "X" if fn_name.endswith("_x") else "W", 2)
+    _need(reorder_index, torch.int16, "reorder_index", 1)
+    rows, KQ = X.shape
+    KE = int(KE)
+    if reorder_index.numel() != KQ:
+        raise RuntimeError(f"agemm: reorder_index has {reorder_index.numel()} entries, expected {KQ}")
+    K = KQ + KE
+    if variant is None:
+        variant = variant_for_kq(KQ)
+    if KQ % 16 or KE % 16 or KE < 0 or KE > KQ or K % 64:
+        raise RuntimeError(f"Value error in {fn_name}: KQ={KQ}, KE={KE} is not valid")
+    Q = torch.empty((rows, K // 2), dtype=torch.uint8, device=X.device)
+    SF = torch.empty((sf_buffer_bytes(rows, K),), dtype=torch.uint8, device=X.device)
+    L = _lib.lib()
+    fn = L.arcq_quantize_x if fn_name.endswith("_x") else L.arcq_quantize_w
+    with torch.cuda.device(X.device):
+        st = fn(X.data_ptr(), reorder_index.data_ptr(), Q.data_ptr(), SF.data_ptr(), rows, KQ, KE, int(variant), _stream(X))
+    _lib.check(st, fn_name)
+    return Q, SF
+
+
+def reorder_quantize_x(X: torch.Tensor, reorder_index: torch.Tensor, KE: int, variant=None):
+    """agemm.reorder_quantize_x(X, reorder_index, KE) -> (QX u8 [M,(KQ+KE)/2], SFX u8 [(M/128+1)*128*(KQ+KE)/16])
+    (bindings.cpp:122-163)."""
+    return _quantize("reorder_quantize_x", X, reorder_index, KE, variant)
+
+
+def reorder_quantize_w(W: torch.Tensor, reorder_index: torch.Tensor, KE: int, variant=None):
+    """agemm.reorder_quantize_w(W, reorder_index, KE) -> (QW, SFW) (bindings.cpp:170-210)."""
+    return _quantize("reorder_quantize_w", W, reorder_index, KE, variant)
+
+
+def rmsnorm_quantize_x(X: torch.Tensor, W: torch.Tensor, eps: float, reorder_index: torch.Tensor, KE: int, variant=None):
+    """agemm.rmsnorm_quantize_x(X, W, eps, reorder_index, KE) -> (QX, SFX) (bindings.cpp:216-254)."""
+    _need(X, torch.bfloat16, "X", 2)
+    _need(W, torch.bfloat16, "W", 1)
+    _need(reorder_index, torch.int16, "reorder_index", 1)
+    M, KQ = X.shape
+    KE = int(KE)
+    K = KQ + KE
+    if W.numel() != KQ or reorder_index.numel() != KQ:
+        raise RuntimeError("agemm: rmsnorm weight / reorder_index length must equal X.shape[1]")
+    if variant is None:
+        variant = variant_for_kq(KQ)
+    if KQ % 16 or KE % 16 or KE < 0 or KE > KQ or K % 64 or not (2048 <= KQ <= 8192):
+        raise RuntimeError(f"Value error in run_rmsnorm_x_bf16_nvfp4: K value is not valid: {KQ}")
+    QX = torch.empty((M, K // 2), dtype=torch.uint8, device=X.device)
+    SFX = torch.empty((sf_buffer_bytes(M, K),), dtype=torch.uint8, device=X.device)
+    with torch.cuda.device(X.device):
+        st = _lib.lib().arcq_rmsnorm_quantize_x(X.data_ptr(), W.data_ptr(), float(eps), reorder_index.data_ptr(), QX.data_ptr(),
+                                                SFX.data_ptr(), M, KQ, KE, int(variant), _stream(X))
+    _lib.check(st, "rmsnorm_quantize_x")
+    return QX, SFX
+
+
+def matmul(A: torch.Tensor, B: torch.Tensor, SFA: torch.Tensor, SFB: torch.Tensor, scale, *, bias=None,
+           out_dtype=torch.bfloat16, out=None):
+    """agemm.matmul(A, B, SFA, SFB, scale) -> bf16 [M, N]  (bindings.cpp:99-120).
+
+    ``scale`` may be a Python float (the reference's ``const float``) or a 0-dim / 1-element fp32 device
+    tensor; the latter is consumed on the device (the reference converts it with an implicit ``.item()``
+    sync).  ``bias`` / ``out_dtype=torch.float32`` / ``out`` are extensions used by the host mirror.
+    """
+    _need(A, torch.uint8, "A", 2)
+    _need(B, torch.uint8, "B", 2)
+    _need(SFA, torch.uint8, "SFA")
+    _need(SFB, torch.uint8, "SFB")
+    M, N, K = A.shape[0], B.shape[0], A.shape[1] * 2       # bindings.cpp:107-109
+    if B.shape[1] * 2 != K:
+        raise RuntimeError(f"agemm.matmul: A has K={K}, B has K={B.shape[1] * 2}")
+    L = _lib.lib()
+    if SFA.numel() < L.arcq_sf_used_bytes(M, K) or SFB.numel() < L.arcq_sf_used_bytes(N, K):
+        raise RuntimeError("agemm.matmul: scale-factor buffer smaller than the swizzled layout of its operand")
+    alpha_host, alpha_dev = 1.0, None
+    if isinstance(scale, torch.Tensor):
+        if scale.is_cuda and scale.dtype == torch.float32 and scale.numel() == 1:
+            alpha_dev = scale
+        else:
+            alpha_host = float(scale)          # CPU tensor or other dtype: same as the reference's __float__
+    else:
+        alpha_host = float(scale)
+    if out_dtype not in (torch.bfloat16, torch.float32):
+        raise RuntimeError("agemm.matmul: out_dtype must be bfloat16 or float32")
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+    else:
+        _need(out, out_dtype, "out", 2)
+        if tuple(out.shape) != (M, N):
+            raise RuntimeError("agemm.matmul: out has the wrong shape")
+    if bias is not None:
+        _need(bias, torch.bfloat16, "bias", 1)
+        if bias.numel() != N:
+            raise RuntimeError("agemm.matmul: bias must have N entries")
+    ws_bytes = int(L.arcq_gemm_workspace_bytes(M, N, K))
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=A.device) if ws_bytes else None
+    with torch.cuda.device(A.device):
+        st = L.arcq_gemm_nvfp4(A.data_ptr(), B.data_ptr(), SFA.data_ptr(), SFB.data_ptr(), out.data_ptr(), M, N, K,
+                               alpha_host, alpha_dev.data_ptr() if alpha_dev is not None else None,
+                               bias.data_ptr() if bias is not None else None,
+                               OUT_BF16 if out_dtype == torch.bfloat16 else OUT_F32,
+                               ws.data_ptr() if ws is not None else None, ws_bytes, _stream(A))
+    _lib.check(st, "matmul")
+    return out
+
+
+def absmax_scale(X: torch.Tensor) -> torch.Tensor:
+    """Extension: ``max|X| / (448*6)`` as a 1-element fp32 device tensor, no host sync.
+    Equals ``torch.max(x.abs()).float() / (448.0*6.0)`` of model/qLlamaLayer.py:74."""
+    _need(X, torch.bfloat16, "X")
+    out = torch.empty((1,), dtype=torch.float32, device=X.device)
+    with torch.cuda.device(X.device):
+        st = _lib.lib().arcq_absmax_scale(X.data_ptr(), X.numel(), out.data_ptr(), _stream(X))
+    _lib.check(st, "absmax_scale")
+    return out
+
+
+# --- KV-cache functions of the reference module (bindings.cpp:576-581): OUT OF SCOPE.
+# Present so that `from model.kv_cache import *` still imports against this module.
+def _kv_stub(name):
+    def f(*args, **kwargs):
+        raise NotImplementedError(f"agemm.{name}: the int4 paged-KV attention is outside the ARC-NVFP4 GEMM hot path")
+    f.__name__ = name
+    return f
+
+
+batch_decode_i4 = _kv_stub("batch_decode_i4")
+init_kv_i4 = _kv_stub("init_kv_i4")
+append_kv_i4 = _kv_stub("append_kv_i4")
+batch_decode_f16 = _kv_stub("batch_decode_f16")
+init_kv_f16 = _kv_stub("init_kv_f16")
+append_kv_f16 = _kv_stub("append_kv_f16")

@@ -1,0 +1,41 @@
+// Internal declarations shared by the translation units of libarcq_hip.so (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/arcq.h"
+
+namespace arcq {
+
+// Records a formatted message for arcq_last_error() (thread-local) and returns `code`.
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// quantize.hip
+int quantize_x(const void* X, const int16_t* idx, uint8_t* QX, uint8_t* SFX, int64_t M, int64_t KQ, int64_t KE, int variant,
+               hipStream_t stream);
+int quantize_w(const void* W, const int16_t* idx, uint8_t* QW, uint8_t* SFW, int64_t N, int64_t KQ, int64_t KE, int variant,
+               hipStream_t stream);
+int rmsnorm_quantize_x(const void* X, const void* Wn, float eps, const int16_t* idx, uint8_t* QX, uint8_t* SFX, int64_t M,
+                       int64_t KQ, int64_t KE, int variant, hipStream_t stream);
+int absmax_scale(const void* X, int64_t n, float* scale_out, hipStream_t stream);
+
+// gemm_skinny.hip / gemm_tile.hip
+struct GemmArgs {
+  const uint8_t* A;     // [M, K/2]
+  const uint8_t* B;     // [N, K/2]
+  const uint8_t* SFA;   // swizzled ue4m3
+  const uint8_t* SFB;
+  void* D;              // [M, N] bf16 or fp32
+  int M, N, K;
+  float alpha_host;
+  const float* alpha_dev;   // optional device scalar multiplied into alpha
+  const uint16_t* bias;     // optional bf16 [N]
+  int out_dtype;
+  void* workspace;
+  int64_t workspace_bytes;
+};
+int64_t gemm_skinny_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int gemm_skinny(const GemmArgs& a, hipStream_t stream);   // M <= 16: weight-streaming MFMA GEMV
+int gemm_tile(const GemmArgs& a, hipStream_t stream);     // general M: LDS-tiled MFMA GEMM
+
+}  // namespace arcq

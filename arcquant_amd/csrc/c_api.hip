@@ -1,0 +1,105 @@
+// extern "C" entry points of libarcq_hip.so (declared in include/arcq.h): argument validation,
+// dispatch between the two GEMM kernels, error text.  No allocation, no synchronisation, no state.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "arcq_device.hpp"
+#include "arcq_internal.hpp"
+
+namespace arcq {
+
+static thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+}  // namespace arcq
+
+using namespace arcq;
+
+extern "C" {
+
+int arcq_abi_version(void) { return ARCQ_ABI_VERSION; }
+const char* arcq_last_error(void) { return g_err; }
+
+// KQ-generic replacement of the closed switch in bindings.cpp:141-160: the reference routes
+// {3584, 18944} to the 32-per-thread kernels and {27648, 28672} to the "down" kernels (same layout);
+// every other size it supports uses the 16-per-thread layout, which is also our default elsewhere.
+int arcq_variant_for_kq(int64_t KQ) {
+  return (KQ == 3584 || KQ == 18944 || KQ == 27648 || KQ == 28672) ? ARCQ_VARIANT_G32 : ARCQ_VARIANT_G16;
+}
+
+int64_t arcq_sf_alloc_bytes(int64_t rows, int64_t K) { return (rows / 128 + 1) * 128 * K / 16; }   // bindings.cpp:83-95
+int64_t arcq_sf_used_bytes(int64_t rows, int64_t K) { return ((rows + 127) / 128) * 128 * K / 16; }
+int64_t arcq_sf_offset(int64_t row, int64_t pos, int64_t K) { return sf_offset(row, pos, K); }
+
+int64_t arcq_primary_pos(int64_t g, int64_t KQ, int64_t KE, int variant) {
+  const int64_t P = (KQ - KE) / 16;
+  if (variant == ARCQ_VARIANT_G16) return g + (g > P ? g - P : 0);
+  const int64_t g1 = g & ~(int64_t)1;
+  return g1 + (g1 > P ? g1 - P : 0) + (g & 1);
+}
+int64_t arcq_residual_pos(int64_t g, int64_t KQ, int64_t KE, int variant) {
+  const int64_t P = (KQ - KE) / 16;
+  if (g < P) return -1;
+  return arcq_primary_pos(g, KQ, KE, variant) + (variant == ARCQ_VARIANT_G16 ? 1 : 2);
+}
+
+int arcq_quantize_x(const void* X, const int16_t* reorder_index, uint8_t* QX, uint8_t* SFX, int64_t M, int64_t KQ, int64_t KE,
+                    int variant, void* stream) {
+  return quantize_x(X, reorder_index, QX, SFX, M, KQ, KE, variant, (hipStream_t)stream);
+}
+
+int arcq_quantize_w(const void* W, const int16_t* reorder_index, uint8_t* QW, uint8_t* SFW, int64_t N, int64_t KQ, int64_t KE,
+                    int variant, void* stream) {
+  return quantize_w(W, reorder_index, QW, SFW, N, KQ, KE, variant, (hipStream_t)stream);
+}
+
+int arcq_rmsnorm_quantize_x(const void* X, const void* W, float eps, const int16_t* reorder_index, uint8_t* QX, uint8_t* SFX,
+                            int64_t M, int64_t KQ, int64_t KE, int variant, void* stream) {
+  return rmsnorm_quantize_x(X, W, eps, reorder_index, QX, SFX, M, KQ, KE, variant, (hipStream_t)stream);
+}
+
+int arcq_absmax_scale(const void* X, int64_t n, float* scale_out, void* stream) {
+  return absmax_scale(X, n, scale_out, (hipStream_t)stream);
+}
+
+static const int64_t kSkinnyMaxM = 16;
+
+int64_t arcq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  return M <= kSkinnyMaxM ? gemm_skinny_workspace_bytes(M, N, K) : 0;
+}
+
+int arcq_gemm_nvfp4(const uint8_t* A, const uint8_t* B, const uint8_t* SFA, const uint8_t* SFB, void* D, int64_t M, int64_t N,
+                    int64_t K, float alpha_host, const float* alpha_dev, const void* bias, int out_dtype, void* workspace,
+                    int64_t workspace_bytes, void* stream) {
+  if (M < 0 || N < 0 || K <= 0 || (K % 64))
+    return fail(ARCQ_ERR_SHAPE, "arcq_gemm_nvfp4: need M,N >= 0 and K %% 64 == 0 (M=%lld N=%lld K=%lld)", (long long)M,
+                (long long)N, (long long)K);
+  if (out_dtype != ARCQ_OUT_BF16 && out_dtype != ARCQ_OUT_F32) return fail(ARCQ_ERR_SHAPE, "arcq_gemm_nvfp4: bad out_dtype %d", out_dtype);
+  if (M == 0 || N == 0) return ARCQ_OK;
+  if (!A || !B || !SFA || !SFB || !D) return fail(ARCQ_ERR_NULL, "arcq_gemm_nvfp4: NULL pointer");
+  if (M > INT32_MAX / 2 || N > INT32_MAX / 2 || K > INT32_MAX / 2 || M * N > ((int64_t)1 << 40))
+    return fail(ARCQ_ERR_UNSUPPORTED, "arcq_gemm_nvfp4: shape too large");
+  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(D)) & 15)
+    return fail(ARCQ_ERR_SHAPE, "arcq_gemm_nvfp4: A, B and D must be 16-byte aligned");
+  if ((reinterpret_cast<uintptr_t>(SFA) | reinterpret_cast<uintptr_t>(SFB)) & 3)
+    return fail(ARCQ_ERR_SHAPE, "arcq_gemm_nvfp4: SFA and SFB must be 4-byte aligned");
+  GemmArgs a;
+  a.A = A; a.B = B; a.SFA = SFA; a.SFB = SFB; a.D = D;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K;
+  a.alpha_host = alpha_host; a.alpha_dev = alpha_dev; a.bias = (const uint16_t*)bias; a.out_dtype = out_dtype;
+  a.workspace = workspace; a.workspace_bytes = workspace_bytes;
+  if (M <= kSkinnyMaxM) return gemm_skinny(a, (hipStream_t)stream);
+  return gemm_tile(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,57 @@
+// Shared device pieces of the two NVFP4 GEMM kernels (gfx950).
+//
+// Why fp16 MFMA: an NVFP4 operand element is e2m1 (2 significant bits) times a ue4m3 block scale
+// (4 significant bits): the product needs up to 6 significant bits and spans [2^-10, 2688], which
+// fp16 holds EXACTLY and in its normal range.  gfx950's block-scaled fp4 MFMA
+// (v_mfma_scale_f32_16x16x128_f8f6f4) applies one power-of-two (E8M0) scale per 32 elements, so it
+// cannot express a 3-mantissa-bit scale per 16; the exact contraction therefore runs on
+// v_mfma_f32_16x16x32_f16 after an in-register dequantisation:
+//     v_cvt_scalef32_pk_f16_fp4   (2 codes -> 2 fp16, probed on MI355X: the scale operand only
+//                                  contributes its exponent, so it is fed 1.0)
+//     v_pk_mul_f16                (x the fp16 copy of the ue4m3 scale; exact)
+// Products of two such fp16 values are exact in fp32, accumulation is the MFMA's fp32 chain.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "arcq_device.hpp"
+
+namespace arcq {
+
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+union Frag8 {        // 8 fp16 = one MFMA 16x16x32 operand fragment = 16 bytes
+  f16x8 v;
+  f16x2 p[4];
+  uint4 u;
+};
+
+// ue4m3 byte -> fp16 pair (s, s).  4 significant bits, range [2^-9, 448]: exact in fp16.
+__device__ __forceinline__ f16x2 sf_pair(uint32_t byte) {
+  _Float16 s = (_Float16)ue4m3_to_f32(byte);
+  f16x2 r = {s, s};
+  return r;
+}
+
+// 8 e2m1 codes (one dword, low nibble first) x scale -> 8 fp16.
+__device__ __forceinline__ Frag8 dequant8(uint32_t codes, f16x2 s2) {
+  Frag8 f;
+  f.p[0] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(codes, 1.0f, 0) * s2;
+  f.p[1] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(codes, 1.0f, 1) * s2;
+  f.p[2] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(codes, 1.0f, 2) * s2;
+  f.p[3] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(codes, 1.0f, 3) * s2;
+  return f;
+}
+
+// Byte offset of the 4 scale bytes (one K-atom of 64 elements) of row r: they are contiguous and
+// 4-byte aligned in the swizzled layout (arcq.h).
+__device__ __forceinline__ int64_t sf_atom_offset(int r, int atom, int atoms_k) {
+  return ((int64_t)(r >> 7) * atoms_k + atom) * 512 + (r & 31) * 16 + ((r >> 5) & 3) * 4;
+}
+
+// alpha*acc (+bias) -> bf16 / fp32 store helpers
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) { return f32_to_bf16_bits(a) | (f32_to_bf16_bits(b) << 16); }
+
+}  // namespace arcq

@@ -1,0 +1,287 @@
+// Reorder + NVFP4 quantise kernels for gfx950 (activation / weight / fused RMSNorm).
+//
+// Replaces kernels/src/reorder.cu (reorder_{x,w}_kernel, reorder32_{x,w}_kernel), kernels/src/down.cu
+// (down32_{x,w}_kernel) and kernels/src/rmsnorm.cu (rmsnorm_x_kernel) of the reference with ONE
+// KQ-generic kernel family: the reference instantiates a template per hidden size and needs a host
+// index_select pre-pass for rows that do not fit 48 KB of static shared memory (bindings.cpp:29-38);
+// a CDNA4 CU has 160 KB of LDS, so every supported row (<= 28672 bf16 = 56 KB) is staged and
+// gathered in LDS directly.
+//
+// Work decomposition (HBM-bound, integer-exact output):
+//   grid  = min(rows, kMaxBlocks) workgroups of 256 threads (4 wave64), each looping over rows
+//   row   -> LDS with 16-byte coalesced loads; thread t owns the 16-element groups t, t+256, ...
+//   group -> gather 16 bf16 from LDS by reorder_index, |max| -> ue4m3 scale -> e2m1 codes -> 8 packed
+//            bytes (one 8-byte store) + 1 scale byte at its swizzled offset; groups in the outlier
+//            tail additionally emit the quantised residual (x) or a duplicate (w).
+//
+// Numerics follow the kernel text of the reference exactly (see oracle/arcq_oracle.c for the CPU
+// restatement these kernels are tested against, byte for byte).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "arcq_device.hpp"
+#include "arcq_internal.hpp"
+
+namespace arcq {
+
+enum : int { kModeX = 0, kModeW = 1, kModeRms = 2 };
+
+constexpr int kQuantThreads = 256;
+
+struct GroupQ {
+  uint2 packed;    // 16 e2m1 codes, low nibble = even element (reorder.cu:28-31)
+  uint32_t s8;     // ue4m3 scale byte
+  float s_round;   // decoded ue4m3 scale
+  float s_raw;     // clamp(amax/6, 2^-9, 448) before rounding
+};
+
+// amax -> scale -> codes for one 16-element group held in registers (reorder.cu:119-164).
+// When kResid, v[] is overwritten with bf16(v - q*S), S = rounded scale (G16) or raw scale (G32).
+template <bool kResid, int kVariant>
+__device__ __forceinline__ GroupQ quantize_group(float (&v)[16]) {
+  float amax = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(v[i]));
+  float s = amax / kFp4Max;                      // IEEE division (hipcc default: correctly rounded)
+  s = fminf(fmaxf(s, kScaleEps), kFp8Max);
+  GroupQ g;
+  g.s_raw = s;
+  g.s8 = f32_to_ue4m3(s);
+  g.s_round = ue4m3_to_f32(g.s8);
+  const float r = 1.0f / g.s_round;              // == (float)(1.0/(double)s8), tests/test_oracle_formats.py
+  const float S = (kVariant == ARCQ_VARIANT_G16) ? g.s_round : g.s_raw;   // reorder.cu:157 vs :474
+  uint32_t lo = 0, hi = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    float q = fminf(fmaxf(v[i] * r, -kFp4Max), kFp4Max);
+    uint32_t c = f32_to_e2m1(q);
+    if (i < 8) lo |= c << (4 * i); else hi |= c << (4 * (i - 8));
+    if (kResid) {
+      float d = __builtin_fmaf(-e2m1_to_f32(c), S, v[i]);   // fused, oracle assumption A2
+      v[i] = bf16_bits_to_f32(f32_to_bf16_bits(d));
+    }
+  }
+  g.packed = make_uint2(lo, hi);
+  return g;
+}
+
+// Sum of squares of one row in the reference's association order (rmsnorm.cu:113-154), so that the
+// fp32 result is bit-identical to the oracle's: virtual thread v in [0, KQ/16) owns the 16-byte
+// chunks v and KQ/16 + v, accumulates their 16 squares sequentially, then a fixed tree.
+// `s` is an LDS array of >= max(512, bdx) floats.  Returns the total in every thread.
+__device__ __forceinline__ float rms_sumsq_tree(float* s, int bdx) {
+  const int tid = threadIdx.x;
+  __syncthreads();
+  for (int stride = 256; stride >= 32; stride >>= 1) {
+    for (int v = tid; v < stride && v < bdx; v += kQuantThreads)
+      if (v + stride < bdx) s[v] = s[v] + s[v + stride];
+    __syncthreads();
+  }
+  float val = (tid < 32 && tid < bdx) ? s[tid] : 0.0f;
+#pragma unroll
+  for (int sh = 16; sh > 0; sh >>= 1) val += __shfl_down(val, sh, 64);   // lane 0's cone = reference's
+  if (tid == 0) s[0] = val;
+  __syncthreads();
+  return s[0];
+}
+
+template <int kVariant, int kMode>
+__global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
+    const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wn, float eps, const int16_t* __restrict__ idx,
+    uint8_t* __restrict__ Q, uint8_t* __restrict__ SF, int rows, int KQ, int KE) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint16_t* row_lds = reinterpret_cast<uint16_t*>(smem);
+  float* red = reinterpret_cast<float*>(smem + (size_t)KQ * 2);   // kModeRms only
+
+  const int tid = threadIdx.x;
+  const int K = KQ + KE;
+  const int G = KQ >> 4;
+  const int P = (KQ - KE) >> 4;
+  const int chunks = KQ >> 3;           // 16-byte chunks per row
+  const int bdx = KQ >> 4;              // the reference's block size (rmsnorm.cu:269-270)
+
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const uint16_t* xrow = X + (size_t)row * KQ;
+    float rstd = 1.0f;
+    if (kMode == kModeRms) {
+      for (int v = tid; v < bdx; v += kQuantThreads) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int c = it * bdx + v;
+          uint4 d = *reinterpret_cast<const uint4*>(xrow + (size_t)c * 8);
+          *reinterpret_cast<uint4*>(row_lds + (size_t)c * 8) = d;
+          const uint32_t w4[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float a = bf16_bits_to_f32(w4[j] & 0xffffu), b = bf16_bits_to_f32(w4[j] >> 16);
+            acc = acc + a * a;
+            acc = acc + b * b;
+          }
+        }
+        red[v] = acc;
+      }
+      float sum = rms_sumsq_tree(red, bdx);
+      float var = sum / (float)KQ + eps;                       // rmsnorm.cu:157
+      rstd = (float)(1.0 / sqrt((double)var));                 // oracle assumption A4
+    } else {
+      for (int c = tid; c < chunks; c += kQuantThreads)
+        *reinterpret_cast<uint4*>(row_lds + (size_t)c * 8) = *reinterpret_cast<const uint4*>(xrow + (size_t)c * 8);
+      __syncthreads();
+    }
+
+    uint8_t* qrow = Q + (size_t)row * (K >> 1);
+    for (int g = tid; g < G; g += kQuantThreads) {
+      // reorder_index for this group: 16 x int16 = two 16-byte loads
+      const uint4 i0 = *reinterpret_cast<const uint4*>(idx + (size_t)g * 16);
+      const uint4 i1 = *reinterpret_cast<const uint4*>(idx + (size_t)g * 16 + 8);
+      const uint32_t iw[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t ia = iw[j] & 0xffffu, ib = iw[j] >> 16;
+        float a = bf16_bits_to_f32(row_lds[ia]), b = bf16_bits_to_f32(row_lds[ib]);
+        if (kMode == kModeRms) {                                // rmsnorm.cu:165-171
+          a = bf16_bits_to_f32(f32_to_bf16_bits(a * bf16_bits_to_f32(Wn[ia]) * rstd));
+          b = bf16_bits_to_f32(f32_to_bf16_bits(b * bf16_bits_to_f32(Wn[ib]) * rstd));
+        }
+        v[2 * j] = a;
+        v[2 * j + 1] = b;
+      }
+      const bool tail = g >= P;
+      // augmented-K position of this group (reorder.cu:139 / :451-452)
+      int p;
+      if (kVariant == ARCQ_VARIANT_G16) {
+        p = g + (g > P ? g - P : 0);
+      } else {
+        const int g1 = g & ~1;
+        p = g1 + (g1 > P ? g1 - P : 0) + (g & 1);
+      }
+      const int pr = p + (kVariant == ARCQ_VARIANT_G16 ? 1 : 2);
+
+      if (kMode == kModeW) {
+        GroupQ q = quantize_group<false, kVariant>(v);
+        *reinterpret_cast<uint2*>(qrow + (size_t)p * 8) = q.packed;
+        SF[sf_offset(row, p, K)] = (uint8_t)q.s8;
+        if (tail) {                                              // duplicate: reorder.cu:306-316, 671-683
+          *reinterpret_cast<uint2*>(qrow + (size_t)pr * 8) = q.packed;
+          SF[sf_offset(row, pr, K)] = (uint8_t)q.s8;
+        }
+      } else if (!tail) {
+        GroupQ q = quantize_group<false, kVariant>(v);
+        *reinterpret_cast<uint2*>(qrow + (size_t)p * 8) = q.packed;
+        SF[sf_offset(row, p, K)] = (uint8_t)q.s8;
+      } else {                                                   // residual: reorder.cu:166-198, 499-550
+        GroupQ q = quantize_group<true, kVariant>(v);
+        *reinterpret_cast<uint2*>(qrow + (size_t)p * 8) = q.packed;
+        SF[sf_offset(row, p, K)] = (uint8_t)q.s8;
+        GroupQ r = quantize_group<false, kVariant>(v);
+        *reinterpret_cast<uint2*>(qrow + (size_t)pr * 8) = r.packed;
+        SF[sf_offset(row, pr, K)] = (uint8_t)r.s8;
+      }
+    }
+    __syncthreads();   // row_lds is rewritten by the next row
+  }
+}
+
+// scale_out[0] = max|x| / 2688 (model/qLlamaLayer.py:73-77 without the host round trip).
+// |bf16| ordering == ordering of the low 15 bits, so an integer atomicMax is exact.
+__global__ __launch_bounds__(256) void absmax_bits_kernel(const uint16_t* __restrict__ X, int64_t n8, int64_t n,
+                                                           unsigned int* __restrict__ slot) {
+  uint32_t m = 0;
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n8; c += (int64_t)gridDim.x * blockDim.x) {
+    uint4 d = *reinterpret_cast<const uint4*>(X + c * 8);
+    const uint32_t w4[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      m = max(m, w4[j] & 0x7fffu);
+      m = max(m, (w4[j] >> 16) & 0x7fffu);
+    }
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = n8 * 8 + threadIdx.x; i < n; i += blockDim.x) m = max(m, (uint32_t)X[i] & 0x7fffu);
+#pragma unroll
+  for (int sh = 32; sh > 0; sh >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, sh, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(slot, m);
+}
+
+__global__ void absmax_finish_kernel(unsigned int* slot, float* scale_out) {
+  // torch's GPU true-divide by a host scalar multiplies by the fp32 reciprocal (BinaryDivTrueKernel):
+  // `torch.max(x.abs()).float() / (448.0*6.0)` == amax * (1.0f / 2688.0f), bit for bit.
+  float amax = bf16_bits_to_f32(*slot);
+  scale_out[0] = amax * (1.0f / (448.0f * 6.0f));
+}
+
+// ----------------------------------------------------------------------------------------------------
+// launchers
+// ----------------------------------------------------------------------------------------------------
+constexpr int kMaxQuantBlocks = 2048;   // 256 CUs x 8 resident workgroups, rows are grid-strided beyond
+
+template <int kMode>
+static int launch_quantize(const void* X, const void* Wn, float eps, const int16_t* idx, uint8_t* Q, uint8_t* SF,
+                           int64_t rows, int64_t KQ, int64_t KE, int variant, hipStream_t stream, const char* who) {
+  if (rows < 0 || KQ <= 0 || (KQ % 16) || (KE % 16) || KE < 0 || KE > KQ || ((KQ + KE) % 64))
+    return fail(ARCQ_ERR_SHAPE, "%s: need KQ%%16==0, KE%%16==0, 0<=KE<=KQ, (KQ+KE)%%64==0 (rows=%lld KQ=%lld KE=%lld)", who,
+                (long long)rows, (long long)KQ, (long long)KE);
+  if (variant != ARCQ_VARIANT_G16 && variant != ARCQ_VARIANT_G32)
+    return fail(ARCQ_ERR_SHAPE, "%s: unknown variant %d", who, variant);
+  if (variant == ARCQ_VARIANT_G32 && ((KQ % 32) || (KE % 32)))
+    return fail(ARCQ_ERR_SHAPE, "%s: the G32 layout needs KQ%%32==0 and KE%%32==0 (KQ=%lld KE=%lld)", who, (long long)KQ,
+                (long long)KE);
+  if (KQ > 32767)   // int16 reorder_index (bindings.cpp:137)
+    return fail(ARCQ_ERR_UNSUPPORTED, "%s: KQ=%lld does not fit an int16 reorder_index", who, (long long)KQ);
+  if (kMode == kModeRms && (KQ < 2048 || KQ > 8192))   // reduction tree of rmsnorm.cu:130-146 is defined for 128..512 threads
+    return fail(ARCQ_ERR_UNSUPPORTED, "%s: KQ=%lld outside the reference's RMSNorm range [2048, 8192]", who, (long long)KQ);
+  if (rows == 0) return ARCQ_OK;
+  if (!X || !idx || !Q || !SF || (kMode == kModeRms && !Wn)) return fail(ARCQ_ERR_NULL, "%s: NULL pointer", who);
+  if (rows > INT32_MAX) return fail(ARCQ_ERR_UNSUPPORTED, "%s: too many rows", who);
+
+  size_t lds = (size_t)KQ * 2 + (kMode == kModeRms ? 512 * sizeof(float) : 0);
+  const int grid = (int)(rows < kMaxQuantBlocks ? rows : kMaxQuantBlocks);
+  auto go = [&](auto kern) -> int {
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "%s: cannot reserve %zu B of LDS: %s", who, lds, hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kQuantThreads), lds, stream, (const uint16_t*)X, (const uint16_t*)Wn, eps, idx,
+                       Q, SF, (int)rows, (int)KQ, (int)KE);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "%s: launch failed: %s", who, hipGetErrorString(e));
+    return ARCQ_OK;
+  };
+  if (variant == ARCQ_VARIANT_G16) return go(quantize_rows_kernel<ARCQ_VARIANT_G16, kMode>);
+  return go(quantize_rows_kernel<ARCQ_VARIANT_G32, kMode>);
+}
+
+int quantize_x(const void* X, const int16_t* idx, uint8_t* QX, uint8_t* SFX, int64_t M, int64_t KQ, int64_t KE, int variant,
+               hipStream_t stream) {
+  return launch_quantize<kModeX>(X, nullptr, 0.f, idx, QX, SFX, M, KQ, KE, variant, stream, "arcq_quantize_x");
+}
+int quantize_w(const void* W, const int16_t* idx, uint8_t* QW, uint8_t* SFW, int64_t N, int64_t KQ, int64_t KE, int variant,
+               hipStream_t stream) {
+  return launch_quantize<kModeW>(W, nullptr, 0.f, idx, QW, SFW, N, KQ, KE, variant, stream, "arcq_quantize_w");
+}
+int rmsnorm_quantize_x(const void* X, const void* Wn, float eps, const int16_t* idx, uint8_t* QX, uint8_t* SFX, int64_t M,
+                       int64_t KQ, int64_t KE, int variant, hipStream_t stream) {
+  return launch_quantize<kModeRms>(X, Wn, eps, idx, QX, SFX, M, KQ, KE, variant, stream, "arcq_rmsnorm_quantize_x");
+}
+
+int absmax_scale(const void* X, int64_t n, float* scale_out, hipStream_t stream) {
+  if (n < 0) return fail(ARCQ_ERR_SHAPE, "arcq_absmax_scale: n < 0");
+  if (!scale_out || (n > 0 && !X)) return fail(ARCQ_ERR_NULL, "arcq_absmax_scale: NULL pointer");
+  if ((reinterpret_cast<uintptr_t>(X) & 15) != 0) return fail(ARCQ_ERR_SHAPE, "arcq_absmax_scale: X must be 16-byte aligned");
+  // the fp32 output slot doubles as the integer max accumulator
+  unsigned int* slot = reinterpret_cast<unsigned int*>(scale_out);
+  hipError_t e = hipMemsetAsync(slot, 0, sizeof(unsigned int), stream);
+  if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_absmax_scale: memset failed: %s", hipGetErrorString(e));
+  const int64_t n8 = n / 8;
+  int64_t want = (n8 + 255) / 256;
+  const int grid = (int)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
+  hipLaunchKernelGGL(absmax_bits_kernel, dim3(grid), dim3(256), 0, stream, (const uint16_t*)X, n8, n, slot);
+  hipLaunchKernelGGL(absmax_finish_kernel, dim3(1), dim3(1), 0, stream, slot, scale_out);
+  e = hipGetLastError();
+  if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_absmax_scale: launch failed: %s", hipGetErrorString(e));
+  return ARCQ_OK;
+}
+
+}  // namespace arcq

@@ -1,0 +1,117 @@
+/*
+ * arcq.h -- C-ABI of the MI355X-native (gfx950) ARC-NVFP4 hot path.
+ *
+ * This is the drop-in boundary: every entry point takes plain device pointers, sizes and a HIP
+ * stream, allocates nothing, keeps no state, and returns an int status.  It replaces what the
+ * reference's pybind11 module `agemm` (kernels/src/bindings.cpp:551-575) reaches through
+ * libtorch + CUTLASS.  Allocation of outputs stays in the host shim (arcquant_amd/agemm.py), with
+ * the reference's sizes (bindings.cpp:83-95,110,133-134,181-182).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name ends in _host
+ *   - bf16 tensors are passed as `const void*` (16-bit patterns), row-major, contiguous
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream, which is what
+ *     the reference launches on: reorder.cu:344, rmsnorm.cu:272)
+ *   - every launch is asynchronous; nothing here synchronises the device
+ *   - status: 0 = ok, negative = error (see ARCQ_ERR_*); arcq_last_error() gives the text of the
+ *     calling thread's last failure
+ *
+ * Layout contract (bit-exact with the reference):
+ *   packed operand   [rows, K/2] u8, byte j = code[2j] | code[2j+1] << 4   (reorder.cu:28-31,161-164)
+ *   scale factors    ue4m3 bytes in the CUTLASS Sm1xx block-scaled layout:
+ *                    off(r,p) = (r/128)*(K/64)*512 + (p/4)*512 + (r%32)*16 + ((r/32)%4)*4 + p%4
+ *                    (reorder.cuh:118-123, reorder.cu:139-143)
+ *   augmented K      K = KQ + KE; group g of the reordered row goes to position
+ *                    G16: g + max(0, g-P), residual/duplicate at +1          (reorder.cu:139,175)
+ *                    G32: pos1 = 2t + max(0, 2t-P) (+g&1), residual at +2    (reorder.cu:451-452,510)
+ *                    with P = (KQ-KE)/16, t = g/2.
+ */
+#ifndef ARCQ_H_
+#define ARCQ_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARCQ_ABI_VERSION 1
+
+#define ARCQ_OK 0
+#define ARCQ_ERR_SHAPE (-1)       /* a dimension violates the contract (K % 64, KE % 16, KE > KQ, ...) */
+#define ARCQ_ERR_UNSUPPORTED (-2) /* valid but not implemented (e.g. rows that do not fit in LDS)        */
+#define ARCQ_ERR_LAUNCH (-3)      /* hipLaunchKernel / hipGetLastError reported a failure               */
+#define ARCQ_ERR_NULL (-4)        /* a required pointer is NULL                                          */
+#define ARCQ_ERR_WORKSPACE (-5)   /* workspace missing or too small (see arcq_gemm_workspace_bytes)     */
+
+/* Augmented-K layout variants.  The reference picks one by KQ in a closed switch
+ * (bindings.cpp:141-160): G32 for {3584, 18944, 27648, 28672}, G16 for its other sizes. */
+#define ARCQ_VARIANT_G16 0 /* reorder.cu:68-330, rmsnorm.cu:68-255 */
+#define ARCQ_VARIANT_G32 1 /* reorder.cu:380-696, down.cu:71-361   */
+
+#define ARCQ_OUT_BF16 0 /* D is bf16 [M,N]  (the reference's only output type, nvfp4.cu:20-23) */
+#define ARCQ_OUT_F32 1  /* D is fp32 [M,N]  (un-rounded alpha*acc: row-parallel partials, tests) */
+
+int arcq_abi_version(void);
+const char *arcq_last_error(void);
+
+/* ---- host-side layout helpers (pure integer arithmetic, no GPU) ------------------------------------ */
+
+/* replaces the KQ switch of bindings.cpp:141-160,189-207: KQ-generic rule with the same answers on the
+ * reference's closed list. */
+int arcq_variant_for_kq(int64_t KQ);
+/* bindings.cpp:83-95 get_sf{a,b}_buffer_size_in_bytes: (rows/128 + 1) * 128 * K / 16 */
+int64_t arcq_sf_alloc_bytes(int64_t rows, int64_t K);
+/* bytes of that buffer a kernel may touch: ceil(rows/128) * 128 * K / 16 */
+int64_t arcq_sf_used_bytes(int64_t rows, int64_t K);
+int64_t arcq_sf_offset(int64_t row, int64_t pos, int64_t K);
+int64_t arcq_primary_pos(int64_t g, int64_t KQ, int64_t KE, int variant);
+int64_t arcq_residual_pos(int64_t g, int64_t KQ, int64_t KE, int variant); /* -1 if none */
+
+/* ---- quantisers ------------------------------------------------------------------------------------ */
+
+/* agemm.reorder_quantize_x (bindings.cpp:122-163; kernels reorder.cu:68-203, 380-555, down.cu:71-233).
+ *   X [M,KQ] bf16, reorder_index [KQ] int16 (a permutation of 0..KQ-1), QX [M,(KQ+KE)/2] u8,
+ *   SFX >= arcq_sf_alloc_bytes(M, KQ+KE) bytes (only the offsets of rows < M are written).
+ *   KQ % 16 == 0, KE % 16 == 0, 0 <= KE <= KQ, (KQ+KE) % 64 == 0; G32 also needs KQ % 32 == KE % 32 == 0. */
+int arcq_quantize_x(const void *X, const int16_t *reorder_index, uint8_t *QX, uint8_t *SFX, int64_t M, int64_t KQ,
+                    int64_t KE, int variant, void *stream);
+
+/* agemm.reorder_quantize_w (bindings.cpp:170-210; kernels reorder.cu:210-330, 562-696, down.cu:240-361):
+ * as above, but the residual slots are copies of the primary codes and scale. */
+int arcq_quantize_w(const void *W, const int16_t *reorder_index, uint8_t *QW, uint8_t *SFW, int64_t N, int64_t KQ,
+                    int64_t KE, int variant, void *stream);
+
+/* agemm.rmsnorm_quantize_x (bindings.cpp:216-254; kernel rmsnorm.cu:68-255):
+ *   xn = bf16(float(x) * float(w) * rsqrt(sum(x^2)/KQ + eps)) gathered by reorder_index, then as
+ *   arcq_quantize_x.  2048 <= KQ <= 8192 (the reference's range).  The reference always uses the G16
+ *   layout here; pass the variant the weights were quantised with (deviation D1). */
+int arcq_rmsnorm_quantize_x(const void *X, const void *W, float eps, const int16_t *reorder_index, uint8_t *QX,
+                            uint8_t *SFX, int64_t M, int64_t KQ, int64_t KE, int variant, void *stream);
+
+/* ---- GEMM ------------------------------------------------------------------------------------------ */
+
+/* Bytes of scratch arcq_gemm_nvfp4 needs for this shape (0 when none). */
+int64_t arcq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
+
+/* agemm.matmul (bindings.cpp:99-120 -> matmul_host_nvfp4_bf16, nvfp4.cu:35-132):
+ *   D[m,n] = alpha * sum_g sfa[m,g]*sfb[n,g] * sum_{k in g} a[m,k]*b[n,k]      (fp32 accumulate, beta = 0)
+ *   A [M,K/2], B [N,K/2] packed e2m1; SFA/SFB swizzled ue4m3; K % 64 == 0.
+ *   alpha = alpha_host * (alpha_dev ? *alpha_dev : 1): the reference takes a host float
+ *   (bindings.cpp:104); alpha_dev lets callers keep the per-tensor scale on the device (no sync).
+ *   bias (optional, bf16 [N]) is added after scaling, before rounding.  out_dtype: ARCQ_OUT_*.
+ *   workspace / workspace_bytes: scratch of at least arcq_gemm_workspace_bytes(M,N,K) (may be NULL if 0). */
+int arcq_gemm_nvfp4(const uint8_t *A, const uint8_t *B, const uint8_t *SFA, const uint8_t *SFB, void *D, int64_t M,
+                    int64_t N, int64_t K, float alpha_host, const float *alpha_dev, const void *bias, int out_dtype,
+                    void *workspace, int64_t workspace_bytes, void *stream);
+
+/* ---- f1 extension: per-tensor scale on the device (replaces torch.max(x.abs())/2688 + x/scale,
+ *      model/qLlamaLayer.py:73-77, with no host sync) ------------------------------------------------- */
+
+/* scale_out[0] = max|x| / (448*6) as fp32; x is bf16 [n]. */
+int arcq_absmax_scale(const void *X, int64_t n, float *scale_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARCQ_H_ */

@@ -1,0 +1,69 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol include/arcq.h
+declares, and its pure-integer layout helpers agree with the oracle.  No kernel is launched."""
+import os
+import re
+
+import pytest
+
+from arcquant_amd import _lib
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "arcq.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(arcq_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_table_agree():
+    assert _declared_symbols() == sorted(_lib.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    for name in _declared_symbols():
+        assert hasattr(L, name), name
+    assert L.arcq_abi_version() == 1
+
+
+def test_layout_helpers_match_oracle():
+    L = _lib.lib()
+    for rows, K in [(0, 64), (1, 4160), (127, 128), (128, 128), (129, 4160), (4096, 4160), (300, 19008)]:
+        assert L.arcq_sf_alloc_bytes(rows, K) == O.sf_alloc_bytes(rows, K)
+        assert L.arcq_sf_used_bytes(rows, K) == O.sf_used_bytes(rows, K)
+    for K in (64, 4160, 3648):
+        for r in (0, 1, 31, 32, 127, 128, 255, 300):
+            for p in range(0, K // 16, 3):
+                assert L.arcq_sf_offset(r, p, K) == O.sf_offset(r, p, K)
+    for variant in (0, 1):
+        for KQ, KE in [(256, 0), (256, 64), (256, 256), (3584, 128), (4096, 64)]:
+            for g in range(KQ // 16):
+                assert L.arcq_primary_pos(g, KQ, KE, variant) == O.primary_pos(g, KQ, KE, variant)
+                assert L.arcq_residual_pos(g, KQ, KE, variant) == O.residual_pos(g, KQ, KE, variant)
+
+
+def test_variant_rule_reproduces_the_reference_dispatch():
+    # bindings.cpp:141-160
+    g16 = [2048, 3072, 4096, 5120, 8192, 11008, 13824, 14336]
+    g32 = [3584, 18944, 27648, 28672]
+    L = _lib.lib()
+    assert all(L.arcq_variant_for_kq(k) == 0 for k in g16)
+    assert all(L.arcq_variant_for_kq(k) == 1 for k in g32)
+    assert L.arcq_variant_for_kq(1024) == 0          # TP shard sizes outside the reference's list
+
+
+def test_bad_arguments_are_rejected_without_a_gpu():
+    L = _lib.lib()
+    # shape validation happens before any HIP call
+    assert L.arcq_quantize_x(None, None, None, None, 4, 40, 0, 0, None) == -1          # KQ % 16
+    assert b"KQ" in L.arcq_last_error()
+    assert L.arcq_quantize_x(None, None, None, None, 4, 4096, 64, 7, None) == -1       # bad variant
+    assert L.arcq_quantize_x(None, None, None, None, 4, 4096, 64, 0, None) == -4       # NULL pointers
+    assert L.arcq_quantize_x(None, None, None, None, 0, 4096, 64, 0, None) == 0        # empty input is fine
+    assert L.arcq_gemm_nvfp4(None, None, None, None, None, 4, 4, 100, 1.0, None, None, 0, None, 0, None) == -1
+    assert L.arcq_gemm_nvfp4(None, None, None, None, None, 0, 4, 128, 1.0, None, None, 0, None, 0, None) == 0
+    assert L.arcq_rmsnorm_quantize_x(None, None, 1e-6, None, None, None, 4, 1024, 0, 0, None) == -2   # outside [2048, 8192]
+    with pytest.raises(_lib.ArcqError):
+        _lib.check(-1, "demo")

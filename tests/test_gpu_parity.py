@@ -1,0 +1,299 @@
+"""GPU parity tests (``-m gpu``): the HIP kernels, called through the C-ABI, against the CPU oracle.
+
+Bar: byte-exact for everything integer (packed codes, scale bytes, their swizzled positions, untouched
+padding); for the GEMM, fp32 output within 1e-3 relative (north-star tolerance; measured error is ~1e-6)
+of the fp64 oracle and bf16 output within one bf16 ulp of the oracle's rounding.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests.util import bits, from_bits, outlier_activations, prescale, random_perm
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _agemm():
+    from arcquant_amd import agemm
+    return agemm
+
+
+def _lib():
+    from arcquant_amd import _lib
+    return _lib
+
+
+def _raw_quantize(kind, x_bits, idx, KE, variant, wn_bits=None, eps=1e-6, fill=0xEE):
+    """Call the C-ABI directly with poisoned output buffers so that untouched bytes are checked too."""
+    L = _lib().lib()
+    X = torch.from_numpy(x_bits.view(np.int16)).to(DEV)
+    I = torch.from_numpy(idx).to(DEV)
+    rows, KQ = x_bits.shape
+    K = KQ + KE
+    Q = torch.full((rows, K // 2), fill, dtype=torch.uint8, device=DEV)
+    SF = torch.full((O.sf_alloc_bytes(rows, K),), fill, dtype=torch.uint8, device=DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    if kind == "x":
+        st = L.arcq_quantize_x(X.data_ptr(), I.data_ptr(), Q.data_ptr(), SF.data_ptr(), rows, KQ, KE, variant, s)
+    elif kind == "w":
+        st = L.arcq_quantize_w(X.data_ptr(), I.data_ptr(), Q.data_ptr(), SF.data_ptr(), rows, KQ, KE, variant, s)
+    else:
+        Wn = torch.from_numpy(wn_bits.view(np.int16)).to(DEV)
+        st = L.arcq_rmsnorm_quantize_x(X.data_ptr(), Wn.data_ptr(), eps, I.data_ptr(), Q.data_ptr(), SF.data_ptr(), rows, KQ, KE,
+                                       variant, s)
+    _lib().check(st, kind)
+    torch.cuda.synchronize()
+    return Q.cpu().numpy(), SF.cpu().numpy()
+
+
+QUANT_CASES = [
+    # rows, KQ, KE, variant
+    (1, 4096, 64, O.G16),          # BASELINE config[1] activation
+    (3, 256, 64, O.G16),
+    (130, 256, 0, O.G16),
+    (257, 2048, 2048, O.G16),      # every group carries a residual
+    (5, 3584, 64, O.G32),          # Qwen2.5-7B hidden
+    (3, 256, 64, O.G32),
+    (4, 18944, 128, O.G32),        # Qwen2.5-7B intermediate
+    (2, 28672, 64, O.G32),         # the reference's "down" kernels (56 KB row in LDS)
+    (7, 14336, 64, O.G16),         # Llama-3-8B intermediate
+    (9, 1024, 64, O.G16),          # TP shard size outside the reference's closed list
+    (300, 4096, 64, O.G16),
+]
+
+
+@pytest.mark.parametrize("rows,KQ,KE,variant", QUANT_CASES)
+@pytest.mark.parametrize("kind", ["x", "w"])
+def test_quantizers_byte_exact(rows, KQ, KE, variant, kind):
+    x, _ = prescale(outlier_activations(rows, KQ, 1000 + rows + KQ))
+    idx = random_perm(KQ, KQ + KE).numpy()
+    xb = bits(x)
+    want_q, want_sf = (O.quantize_x if kind == "x" else O.quantize_w)(xb, idx, KE, variant, sf_fill=0xEE)
+    got_q, got_sf = _raw_quantize(kind, xb, idx, KE, variant)
+    assert np.array_equal(got_q, want_q), f"packed codes differ in {(got_q != want_q).sum()} bytes"
+    assert np.array_equal(got_sf, want_sf), f"scale bytes differ in {(got_sf != want_sf).sum()} places"
+
+
+def test_quantizer_special_values_byte_exact():
+    """zeros, negative zeros, tiny values (scale floor 2^-9), exact e2m1 ties, saturation at 448*6."""
+    KQ = 256
+    x = torch.zeros(8, KQ, dtype=torch.bfloat16)
+    x[1] = -0.0
+    x[2] = 1e-5
+    x[3, :8] = torch.tensor([0.25, 0.75, 1.25, 1.75, 2.5, 3.5, 5.0, 6.0])
+    x[3, 8:16] = -x[3, :8]
+    x[4] = 2688.0
+    x[5, ::2] = 3e4                       # beyond 448*6: scale clamps at 448
+    x[6] = torch.linspace(-7, 7, KQ).to(torch.bfloat16)
+    x[7] = torch.linspace(0, 0.05, KQ).to(torch.bfloat16)
+    idx = np.arange(KQ, dtype=np.int16)
+    for variant in (O.G16, O.G32):
+        for kind, fn in (("x", O.quantize_x), ("w", O.quantize_w)):
+            want = fn(bits(x), idx, 64, variant, sf_fill=0xEE)
+            got = _raw_quantize(kind, bits(x), idx, 64, variant)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
+@pytest.mark.parametrize("rows,KQ,KE,variant", [(4, 2048, 64, O.G16), (3, 3584, 64, O.G16), (3, 3584, 64, O.G32),
+                                                 (130, 4096, 0, O.G16), (2, 8192, 128, O.G16), (5, 5120, 64, O.G16)])
+def test_rmsnorm_quantizer_byte_exact(rows, KQ, KE, variant):
+    x = outlier_activations(rows, KQ, 77 + KQ)
+    wn = (torch.rand(KQ, generator=torch.Generator().manual_seed(KQ)) + 0.5).to(torch.bfloat16)
+    idx = random_perm(KQ, 3 * KQ).numpy()
+    want = O.rmsnorm_quantize_x(bits(x), bits(wn), 1e-6, idx, KE, variant, sf_fill=0xEE)
+    got = _raw_quantize("rms", bits(x), idx, KE, variant, wn_bits=bits(wn))
+    assert np.array_equal(got[0], want[0]), f"{(got[0] != want[0]).sum()} code bytes differ"
+    assert np.array_equal(got[1], want[1])
+
+
+def test_golden_pins_on_gpu(golden):
+    g = golden("oracle_pins.npz")
+    for tag in ("g16_a", "g16_b", "g16_c", "g32_a", "g32_b"):
+        M, KQ, KE, variant = (int(v) for v in g[f"{tag}_meta"])
+        qx, sfx = _raw_quantize("x", g[f"{tag}_x"], g[f"{tag}_idx"], KE, variant, fill=0)
+        qw, sfw = _raw_quantize("w", g[f"{tag}_x"], g[f"{tag}_idx"], KE, variant, fill=0)
+        assert np.array_equal(qx, g[f"{tag}_qx"]) and np.array_equal(sfx, g[f"{tag}_sfx"])
+        assert np.array_equal(qw, g[f"{tag}_qw"]) and np.array_equal(sfw, g[f"{tag}_sfw"])
+    ag = _agemm()
+    A = torch.from_numpy(g["rms_qx"]).to(DEV)
+    B = torch.from_numpy(g["rms_qw"]).to(DEV)
+    SFA = torch.from_numpy(g["rms_sfx"]).to(DEV)
+    SFB = torch.from_numpy(g["rms_sfw"]).to(DEV)
+    d32 = ag.matmul(A, B, SFA, SFB, 0.0123, out_dtype=torch.float32).cpu().numpy().astype(np.float64)
+    assert np.allclose(d32, g["rms_d_exact"], rtol=1e-3, atol=1e-6)
+    d16 = bits(ag.matmul(A, B, SFA, SFB, 0.0123))
+    assert _max_bf16_ulp_diff(d16, g["rms_d_bf16"]) <= 1
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def _max_bf16_ulp_diff(a_bits, b_bits):
+    def key(b):  # monotone integer key of a bf16 bit pattern
+        b = b.astype(np.int32)
+        return np.where(b & 0x8000, -(b & 0x7FFF), b & 0x7FFF)
+    return int(np.abs(key(a_bits) - key(b_bits)).max()) if a_bits.size else 0
+
+
+def _make_operands(M, N, KQ, KE, variant, seed):
+    x, sx = prescale(outlier_activations(M, KQ, seed))
+    w, sw = prescale((torch.rand(N, KQ, generator=torch.Generator().manual_seed(seed + 1)) * 3 - 1.0).to(torch.bfloat16))
+    idx = random_perm(KQ, seed + 2).numpy()
+    qx, sfx = O.quantize_x(bits(x), idx, KE, variant, sf_fill=0)
+    qw, sfw = O.quantize_w(bits(w), idx, KE, variant, sf_fill=0)
+    return qx, sfx, qw, sfw, float(sx * sw)
+
+
+GEMM_CASES = [
+    # M, N, KQ, KE, variant
+    (1, 4096, 4096, 64, O.G16),       # BASELINE config[1]
+    (1, 48, 256, 0, O.G16),
+    (4, 1024, 2048, 64, O.G16),       # kv-proj-like: split-K path
+    (16, 100, 256, 64, O.G16),        # N not a multiple of 16 / 4
+    (3, 3584, 3584, 64, O.G32),
+    (17, 128, 256, 64, O.G16),        # first M on the tile kernel
+    (64, 256, 512, 64, O.G16),
+    (130, 200, 256, 0, O.G16),        # ragged M and N on the tile kernel
+    (128, 384, 1024, 128, O.G32),
+    (300, 130, 320, 0, O.G16),        # N % 4 != 0 (scalar store path)
+]
+
+
+@pytest.mark.parametrize("M,N,KQ,KE,variant", GEMM_CASES)
+def test_gemm_matches_oracle(M, N, KQ, KE, variant):
+    ag = _agemm()
+    qx, sfx, qw, sfw, alpha = _make_operands(M, N, KQ, KE, variant, 500 + M + N)
+    want_bf16, want_exact, want_abs = O.gemm(qx, qw, sfx, sfw, alpha, want_abs=True)
+    A, B = torch.from_numpy(qx).to(DEV), torch.from_numpy(qw).to(DEV)
+    SFA, SFB = torch.from_numpy(sfx).to(DEV), torch.from_numpy(sfw).to(DEV)
+    d32 = ag.matmul(A, B, SFA, SFB, alpha, out_dtype=torch.float32).cpu().numpy().astype(np.float64)
+    # fp32 accumulation of exact products: error is bounded relative to sum|a*b|
+    err = np.abs(d32 - want_exact)
+    assert np.all(err <= 2e-6 * want_abs + 1e-30), float((err / (want_abs + 1e-30)).max())
+    # north-star tolerance: 1e-3 relative (norm-wise, and element-wise away from cancellation)
+    assert np.linalg.norm(d32 - want_exact) <= 1e-3 * np.linalg.norm(want_exact)
+    big = np.abs(want_exact) > 1e-2 * want_abs
+    assert np.all(err[big] <= 1e-3 * np.abs(want_exact[big]))
+    # bf16 output: same rounding as the oracle up to accumulation-order noise
+    d16 = bits(ag.matmul(A, B, SFA, SFB, alpha))
+    assert _max_bf16_ulp_diff(d16, want_bf16) <= 1
+    assert (d16 == want_bf16).mean() > 0.99
+    # device-resident scale (no host sync) gives the same bits as the host float
+    alpha_dev = torch.tensor([alpha], dtype=torch.float32, device=DEV)
+    d16_dev = bits(ag.matmul(A, B, SFA, SFB, alpha_dev))
+    assert np.array_equal(d16_dev, d16)
+
+
+def test_gemm_bias_and_empty():
+    ag = _agemm()
+    qx, sfx, qw, sfw, alpha = _make_operands(5, 64, 256, 64, O.G16, 9)
+    A, B = torch.from_numpy(qx).to(DEV), torch.from_numpy(qw).to(DEV)
+    SFA, SFB = torch.from_numpy(sfx).to(DEV), torch.from_numpy(sfw).to(DEV)
+    bias = torch.randn(64, generator=torch.Generator().manual_seed(1)).to(torch.bfloat16).to(DEV)
+    base = ag.matmul(A, B, SFA, SFB, alpha, out_dtype=torch.float32)
+    withb = ag.matmul(A, B, SFA, SFB, alpha, out_dtype=torch.float32, bias=bias)
+    assert torch.allclose(withb, base + bias.float(), rtol=0, atol=1e-5 * float(base.abs().max()))
+    empty = ag.matmul(A[:0], B, SFA, SFB, alpha)
+    assert tuple(empty.shape) == (0, 64)
+
+
+def test_full_pipeline_against_oracle_pipeline():
+    """reorder_quantize_x + reorder_quantize_w + matmul through the agemm mirror == oracle end to end,
+    on the reference's own check (kernels/main.py:7-48) at reduced M."""
+    ag = _agemm()
+    M, N, KQ = 32, 512, 4096
+    x = outlier_activations(M, KQ, 45510)
+    w = (torch.rand(N, KQ, generator=torch.Generator().manual_seed(45510)) * 3).to(torch.bfloat16)
+    idx = torch.arange(KQ, dtype=torch.int16)
+    xs, sx = prescale(x)
+    ws, sw = prescale(w)
+    ref = (x.float() @ w.float().T).numpy()
+    prev = None
+    for KE in (0, 256, 1024, 4096):
+        A, SFA = ag.reorder_quantize_x(xs.to(DEV), idx.to(DEV), KE)
+        B, SFB = ag.reorder_quantize_w(ws.to(DEV), idx.to(DEV), KE)
+        C = ag.matmul(A, B, SFA, SFB, float(sx * sw), out_dtype=torch.float32).cpu().numpy()
+        oq, osf = O.quantize_x(bits(xs), idx.numpy(), KE, O.G16)
+        ow, owsf = O.quantize_w(bits(ws), idx.numpy(), KE, O.G16)
+        assert np.array_equal(A.cpu().numpy(), oq) and np.array_equal(B.cpu().numpy(), ow)
+        _, want = O.gemm(oq, ow, osf, owsf, float(sx * sw))
+        assert np.linalg.norm(C - want) <= 1e-5 * np.linalg.norm(want)
+        mse = float(np.mean((C - ref) ** 2))
+        assert prev is None or mse < prev         # MSE(k) falls as KE grows, as the reference prints
+        prev = mse
+
+
+def test_absmax_scale_matches_torch():
+    ag = _agemm()
+    for n in (8, 1000, 4096 * 33 + 5):
+        x = (torch.randn(n, generator=torch.Generator().manual_seed(n)) * 37).to(torch.bfloat16).to(DEV)
+        got = ag.absmax_scale(x)
+        want = torch.max(x.abs()).float() / (448.0 * 6.0)
+        assert got.item() == want.item()
+
+
+def test_unsupported_shapes_raise_runtime_error():
+    ag = _agemm()
+    x = torch.zeros(2, 4000, dtype=torch.bfloat16, device=DEV)         # (KQ+KE) % 64 != 0
+    with pytest.raises(RuntimeError):
+        ag.reorder_quantize_x(x, torch.arange(4000, dtype=torch.int16, device=DEV), 0)
+    x = torch.zeros(2, 4096, dtype=torch.float16, device=DEV)          # wrong dtype (reference: c10::Error)
+    with pytest.raises(RuntimeError):
+        ag.reorder_quantize_x(x, torch.arange(4096, dtype=torch.int16, device=DEV), 0)
+    with pytest.raises(NotImplementedError):
+        ag.batch_decode_i4()
+
+
+# ------------------------------------------------------------------------------------------------ full size
+def _torch_dequant(Q, SF, K):
+    """Independent (torch, on the GPU) statement of the format spec, validated against the oracle below."""
+    rows = Q.shape[0]
+    lut = torch.tensor([0, .5, 1, 1.5, 2, 3, 4, 6, -0., -.5, -1, -1.5, -2, -3, -4, -6], dtype=torch.float64, device=Q.device)
+    codes = torch.stack([Q & 0xF, Q >> 4], dim=-1).reshape(rows, K).long()
+    r = torch.arange(rows, device=Q.device).unsqueeze(1)
+    p = torch.arange(K // 16, device=Q.device).unsqueeze(0)
+    off = ((r // 128) * (K // 64) + p // 4) * 512 + (r % 32) * 16 + ((r // 32) % 4) * 4 + p % 4
+    sf = SF[off].view(torch.float8_e4m3fn).to(torch.float64)
+    return lut[codes] * sf.repeat_interleave(16, dim=1)
+
+
+def test_torch_dequant_helper_matches_oracle():
+    qx, sfx, _, _, _ = _make_operands(130, 16, 256, 64, O.G16, 4)
+    got = _torch_dequant(torch.from_numpy(qx).to(DEV), torch.from_numpy(sfx).to(DEV), 320).cpu().numpy()
+    assert np.array_equal(got, O.dequant(qx, sfx).astype(np.float64))
+
+
+@pytest.mark.parametrize("M", [1, 4096])
+def test_baseline_size_gemm_against_fp64_matmul(M):
+    """BASELINE.json sizes (N = KQ = 4096, KE = 64; M = 1 and M = 4096): quantise on the GPU (checked
+    byte-exact against the oracle, which is fast enough for that), then compare the GEMM with an fp64
+    matmul of the dequantised operands computed by torch on the GPU."""
+    ag = _agemm()
+    N = KQ = 4096
+    KE = 64
+    x, sx = prescale(outlier_activations(M, KQ, 45510))
+    w, sw = prescale((torch.rand(N, KQ, generator=torch.Generator().manual_seed(7)) * 3).to(torch.bfloat16))
+    idx = random_perm(KQ, 8)
+    A, SFA = ag.reorder_quantize_x(x.to(DEV), idx.to(DEV), KE)
+    B, SFB = ag.reorder_quantize_w(w.to(DEV), idx.to(DEV), KE)
+    oq, osf = O.quantize_x(bits(x), idx.numpy(), KE, O.G16)
+    ow, owsf = O.quantize_w(bits(w), idx.numpy(), KE, O.G16)
+    assert np.array_equal(A.cpu().numpy(), oq) and np.array_equal(B.cpu().numpy(), ow)
+    K = KQ + KE
+    used_a, used_b = O.sf_used_bytes(M, K), O.sf_used_bytes(N, K)
+    a64 = _torch_dequant(torch.from_numpy(oq).to(DEV), torch.from_numpy(osf).to(DEV), K)
+    b64 = _torch_dequant(torch.from_numpy(ow).to(DEV), torch.from_numpy(owsf).to(DEV), K)
+    assert np.array_equal(B.cpu().numpy(), ow) and used_a <= SFA.numel() and used_b <= SFB.numel()
+    alpha = float(sx * sw)
+    want = alpha * (a64 @ b64.T)
+    got = ag.matmul(A, B, SFA, SFB, alpha, out_dtype=torch.float32).double()
+    rel = (got - want).norm() / want.norm()
+    assert rel < 1e-5, float(rel)
+    # linearity in alpha (power-of-two factor: exact) and bf16 rounding of the same accumulators
+    got2 = ag.matmul(A, B, SFA, SFB, 2.0 * alpha, out_dtype=torch.float32).double()
+    assert torch.equal(got2, 2.0 * got)
+    d16 = ag.matmul(A, B, SFA, SFB, alpha)
+    assert torch.equal(d16, got.float().to(torch.bfloat16))
