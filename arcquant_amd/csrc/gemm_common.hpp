@@ -21,6 +21,7 @@ namespace arcq {
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 union Frag8 {        // 8 fp16 = one MFMA 16x16x32 operand fragment = 16 bytes
   f16x8 v;

@@ -16,6 +16,7 @@
 //     (alpha, optional bias, bf16 rounding) unless split-K needs the second pass.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "arcq_internal.hpp"
 #include "gemm_common.hpp"
@@ -66,7 +67,7 @@ __device__ __forceinline__ void finish4(const SkinnyParams& p, int m, int n, con
   store_out4(p, m, n, d);
 }
 
-template <int kWaves, int kUnroll>
+template <int kWaves, int kUnroll, int kDbg = 0>
 __global__ __launch_bounds__(kWaves * 64) void gemm_skinny_kernel(SkinnyParams p) {
   __shared__ float red[kWaves][64][4];
 
@@ -111,6 +112,15 @@ __global__ __launch_bounds__(kWaves * 64) void gemm_skinny_kernel(SkinnyParams p
       const uint32_t sav = *reinterpret_cast<const uint32_t*>(asf + (size_t)at * 512);
       bs[u] = (live && n_ok) ? sbv : 0u;
       as[u] = (live && m_ok) ? sav : 0u;
+    }
+    // Every load of this pass is issued before the first use: hipcc otherwise sinks each chunk's loads next
+    // to its MFMAs and the wave pays one HBM round trip per chunk instead of one per pass.
+    __builtin_amdgcn_sched_barrier(0);
+    if (kDbg == 1) {   // tuning aid: loads only (keep them live), no dequantisation / MFMA
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u)
+        acc[0] += __uint_as_float((bq[u].x ^ bq[u].y ^ bq[u].z ^ bq[u].w ^ aq[u].x ^ aq[u].w ^ bs[u] ^ as[u]) & 0x3fffffffu);
+      continue;
     }
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
@@ -162,15 +172,26 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(SkinnyParams p, int 
   finish4(p, m, n, s);
 }
 
+// ARCQ_SKINNY_WAVES (tuning only): waves per workgroup, 8 or 16
+static int skinny_waves_override() {
+  static const int v = [] {
+    const char* e = getenv("ARCQ_SKINNY_WAVES");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+
 static void choose_split(int64_t M, int64_t N, int64_t K, int* waves, int* splitk) {
   (void)M;
   const int64_t tiles = (N + 15) / 16;
   const int64_t nchunks = (K + 127) / 128;
-  *waves = 8;
+  int w = skinny_waves_override();
+  if (w != 8 && w != 16) w = (tiles <= 512) ? 16 : 8;   // few tiles: more waves per tile keep more loads in flight
+  *waves = w;
   int s = 1;
-  // fill ~256 CUs with at least one workgroup each, but keep >= 2 chunks per wave; split-K needs N % 4 == 0
+  // fill ~256 CUs with at least one workgroup each, but keep >= 1 chunk per wave; split-K needs N % 4 == 0
   if ((N % 4) == 0) {
-    while (tiles * s < 256 && nchunks / (8 * (s * 2)) >= 2 && s < 16) s *= 2;
+    while (tiles * s < 256 && nchunks / (w * (s * 2)) >= 1 && s < 16) s *= 2;
   }
   *splitk = s;
 }
@@ -196,7 +217,11 @@ int gemm_skinny(const GemmArgs& a, hipStream_t stream) {
                   (long long)a.workspace_bytes);
   }
   const dim3 grid((unsigned)((a.N + 15) / 16), (unsigned)splitk);
-  hipLaunchKernelGGL((gemm_skinny_kernel<8, 4>), grid, dim3(8 * 64), 0, stream, p);
+  static const int dbg = getenv("ARCQ_SKINNY_DBG") ? atoi(getenv("ARCQ_SKINNY_DBG")) : 0;
+  if (dbg == 1 && waves == 16) hipLaunchKernelGGL((gemm_skinny_kernel<16, 3, 1>), grid, dim3(16 * 64), 0, stream, p);
+  else if (dbg == 1) hipLaunchKernelGGL((gemm_skinny_kernel<8, 4, 1>), grid, dim3(8 * 64), 0, stream, p);
+  else if (waves == 16) hipLaunchKernelGGL((gemm_skinny_kernel<16, 3>), grid, dim3(16 * 64), 0, stream, p);
+  else hipLaunchKernelGGL((gemm_skinny_kernel<8, 4>), grid, dim3(8 * 64), 0, stream, p);
   if (splitk > 1) {
     const int64_t quads = ((int64_t)a.M * a.N + 3) / 4;
     hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p, splitk);

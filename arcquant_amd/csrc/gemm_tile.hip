@@ -16,6 +16,9 @@
 // before the MFMAs of step k and written to the other buffer after them.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <type_traits>
 
 #include "arcq_internal.hpp"
 #include "gemm_common.hpp"
@@ -39,48 +42,55 @@ struct TileParams {
 constexpr int kBK = 64;                 // K elements per step = one scale-factor atom column (4 groups)
 constexpr int kRowBytes = kBK * 2;      // fp16 row of a tile in LDS
 
-// byte offset of 16-byte slot `ks` (0..7) of tile row `r`; the XOR spreads the 16 lanes of a
-// ds_read_b128 group over all 16 slots of the 256-byte bank row (conflict-free for MFMA fragments)
-__device__ __forceinline__ int lds_slot(int r, int ks) { return r * kRowBytes + ((ks ^ ((r >> 1) & 7)) << 4); }
+// Byte offset of 16-byte slot `ks` (0..7) of tile row `r`.  XOR with (r & 7):
+//   * ds_read_b128 of an MFMA fragment (16 rows x one slot per 16-lane group) touches all 16 slots of the
+//     256-byte bank row exactly once  -> conflict-free;
+//   * ds_write_b128 of the staging pass (8-lane groups = 4 rows x 2 halves) touches all 8 slots of the
+//     128-byte write bank period exactly once -> conflict-free.
+// The term is invariant under r += 16, so fragment tile i is a constant byte offset from tile 0.
+__device__ __forceinline__ int lds_slot(int r, int ks) { return r * kRowBytes + ((ks ^ (r & 7)) << 4); }
+// Variant for 32-row MFMA fragments (v_mfma_f32_32x32x16_f16): a 16-lane ds_read_b128 group then spans rows
+// {0-3,12-15,20-27} of ONE slot, which needs ((r >> 1) & 7) to stay conflict-free (invariant under r += 32).
+__device__ __forceinline__ int lds_slot32(int r, int ks) { return r * kRowBytes + ((ks ^ ((r >> 1) & 7)) << 4); }
 
 // One staging unit = 16 packed bytes (32 elements, two scale groups) of one tile row.
 struct Staged {
   uint4 q;
-  uint32_t sf;   // the two scale bytes in bits [15:0]
+  uint32_t sf;   // the two scale bytes in bits [15:0] (0 for rows outside the matrix)
 };
 
-__device__ __forceinline__ Staged stage_load(const uint8_t* Q, const uint8_t* SF, int row, int rows, int half_k, int atoms_k,
-                                             int atom, int half) {
+// Unconditional loads (row clamped into the matrix, dead rows neutralised through their scale bytes at
+// dequantisation time): nothing here waits on a load, so the prefetch stays in flight across the MFMAs.
+__device__ __forceinline__ Staged stage_load(const uint8_t* __restrict__ qrow, const uint8_t* __restrict__ sfrow, int atom) {
   Staged s;
-  const int rc = row < rows ? row : rows - 1;          // clamp, neutralise through the scale bytes
-  s.q = *reinterpret_cast<const uint4*>(Q + (size_t)rc * half_k + atom * 32 + half * 16);
-  const uint32_t v = *reinterpret_cast<const uint16_t*>(SF + sf_atom_offset(rc, atom, atoms_k) + half * 2);
-  s.sf = row < rows ? v : 0u;
+  s.q = *reinterpret_cast<const uint4*>(qrow + (size_t)atom * 32);
+  s.sf = *reinterpret_cast<const uint16_t*>(sfrow + (size_t)atom * 512);
   return s;
 }
 
-__device__ __forceinline__ void stage_store(unsigned char* tile, int r, int half, const Staged& s) {
-  const f16x2 s0 = sf_pair(s.sf & 0xffu), s1 = sf_pair((s.sf >> 8) & 0xffu);
+__device__ __forceinline__ void stage_store(unsigned char* tile, const int (&slot)[4], const Staged& s, uint32_t live_mask) {
+  const uint32_t sf = s.sf & live_mask;
+  const f16x2 s0 = sf_pair(sf & 0xffu), s1 = sf_pair((sf >> 8) & 0xffu);
   Frag8 f0 = dequant8(s.q.x, s0), f1 = dequant8(s.q.y, s0), f2 = dequant8(s.q.z, s1), f3 = dequant8(s.q.w, s1);
-  *reinterpret_cast<uint4*>(tile + lds_slot(r, half * 4 + 0)) = f0.u;
-  *reinterpret_cast<uint4*>(tile + lds_slot(r, half * 4 + 1)) = f1.u;
-  *reinterpret_cast<uint4*>(tile + lds_slot(r, half * 4 + 2)) = f2.u;
-  *reinterpret_cast<uint4*>(tile + lds_slot(r, half * 4 + 3)) = f3.u;
+  *reinterpret_cast<uint4*>(tile + slot[0]) = f0.u;
+  *reinterpret_cast<uint4*>(tile + slot[1]) = f1.u;
+  *reinterpret_cast<uint4*>(tile + slot[2]) = f2.u;
+  *reinterpret_cast<uint4*>(tile + slot[3]) = f3.u;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool kMfma32>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TileParams p) {
   constexpr int kThreads = WAVES_M * WAVES_N * 64;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;     // wave tile
-  constexpr int TM = WM / 16, TN = WN / 16;               // MFMA tiles per wave
-  // 16-byte staging units (2 per tile row) per thread; when a tile has fewer units than threads the
-  // surplus waves skip it (wave-uniform guard)
-  constexpr int A_UNITS = (BM * 2 + kThreads - 1) / kThreads, B_UNITS = (BN * 2 + kThreads - 1) / kThreads;
+  constexpr int kT = kMfma32 ? 32 : 16;                   // MFMA tile edge
+  constexpr int TM = WM / kT, TN = WN / kT;               // MFMA tiles per wave
+  using acc_t = typename std::conditional<kMfma32, f32x16, f32x4>::type;
+  static_assert((BM * 2) % kThreads == 0 && (BN * 2) % kThreads == 0, "whole staging units per thread");
+  constexpr int A_UNITS = BM * 2 / kThreads, B_UNITS = BN * 2 / kThreads;   // 16-byte staging units per thread
   constexpr int A_TILE = BM * kRowBytes, B_TILE = BN * kRowBytes;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // [buf][A | B]
-  unsigned char* const lds_a0 = smem;
+  unsigned char* const lds_a0 = smem;                        // [buf][A | B]
   unsigned char* const lds_b0 = smem + A_TILE;
   unsigned char* const lds_a1 = smem + A_TILE + B_TILE;
   unsigned char* const lds_b1 = smem + 2 * A_TILE + B_TILE;
@@ -107,101 +117,163 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
   const int wr = wave / WAVES_N, wc = wave % WAVES_N;
   const int half_k = p.K >> 1, atoms_k = p.K >> 6;
 
-  f32x4 acc[TM][TN];
+  // ---- per-thread staging geometry (loop invariant)
+  const uint8_t* a_q[A_UNITS];
+  const uint8_t* a_sf[A_UNITS];
+  uint32_t a_live[A_UNITS];
+  int a_slot[A_UNITS][4];
+#pragma unroll
+  for (int u = 0; u < A_UNITS; ++u) {
+    const int unit = tid + u * kThreads, r = unit >> 1, h = unit & 1;
+    const int row = m0 + r, rc = row < p.M ? row : p.M - 1;
+    a_q[u] = p.A + (size_t)rc * half_k + h * 16;
+    a_sf[u] = p.SFA + sf_atom_offset(rc, 0, atoms_k) + h * 2;
+    a_live[u] = row < p.M ? 0xffffu : 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a_slot[u][j] = kMfma32 ? lds_slot32(r, h * 4 + j) : lds_slot(r, h * 4 + j);
+  }
+  const uint8_t* b_q[B_UNITS];
+  const uint8_t* b_sf[B_UNITS];
+  uint32_t b_live[B_UNITS];
+  int b_slot[B_UNITS][4];
+#pragma unroll
+  for (int u = 0; u < B_UNITS; ++u) {
+    const int unit = tid + u * kThreads, r = unit >> 1, h = unit & 1;
+    const int row = n0 + r, rc = row < p.N ? row : p.N - 1;
+    b_q[u] = p.B + (size_t)rc * half_k + h * 16;
+    b_sf[u] = p.SFB + sf_atom_offset(rc, 0, atoms_k) + h * 2;
+    b_live[u] = row < p.N ? 0xffffu : 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b_slot[u][j] = kMfma32 ? lds_slot32(r, h * 4 + j) : lds_slot(r, h * 4 + j);
+  }
+  // fragment read offsets: one base per operand; tile i adds i*16 rows (the swizzle term is invariant under
+  // +16 rows) and the second half of K flips bit 2 of the slot index, i.e. byte-offset bit 6
+  const int fa_base = kMfma32 ? lds_slot32(wr * WM + (lane & 31), lane >> 5) : lds_slot(wr * WM + (lane & 15), lane >> 4);
+  const int fb_base = kMfma32 ? lds_slot32(wc * WN + (lane & 31), lane >> 5) : lds_slot(wc * WN + (lane & 15), lane >> 4);
+  acc_t acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < (kMfma32 ? 16 : 4); ++r) acc[i][j][r] = 0.f;
 
-  Staged sa[A_UNITS], sb[B_UNITS];
+  Staged sa[A_UNITS], sb[B_UNITS];     // registers holding step kt+1 while step kt is multiplied
   auto load_step = [&](int atom) {
 #pragma unroll
-    for (int u = 0; u < A_UNITS; ++u) {
-      const int unit = tid + u * kThreads;
-      if (unit < BM * 2) sa[u] = stage_load(p.A, p.SFA, m0 + (unit >> 1), p.M, half_k, atoms_k, atom, unit & 1);
-    }
+    for (int u = 0; u < A_UNITS; ++u) sa[u] = stage_load(a_q[u], a_sf[u], atom);
 #pragma unroll
-    for (int u = 0; u < B_UNITS; ++u) {
-      const int unit = tid + u * kThreads;
-      if (unit < BN * 2) sb[u] = stage_load(p.B, p.SFB, n0 + (unit >> 1), p.N, half_k, atoms_k, atom, unit & 1);
-    }
+    for (int u = 0; u < B_UNITS; ++u) sb[u] = stage_load(b_q[u], b_sf[u], atom);
   };
   auto store_step = [&](unsigned char* la, unsigned char* lb) {
 #pragma unroll
-    for (int u = 0; u < A_UNITS; ++u) {
-      const int unit = tid + u * kThreads;
-      if (unit < BM * 2) stage_store(la, unit >> 1, unit & 1, sa[u]);
-    }
+    for (int u = 0; u < A_UNITS; ++u) stage_store(la, a_slot[u], sa[u], a_live[u]);
 #pragma unroll
-    for (int u = 0; u < B_UNITS; ++u) {
-      const int unit = tid + u * kThreads;
-      if (unit < BN * 2) stage_store(lb, unit >> 1, unit & 1, sb[u]);
-    }
+    for (int u = 0; u < B_UNITS; ++u) stage_store(lb, b_slot[u], sb[u], b_live[u]);
   };
   auto mma_step = [&](const unsigned char* la, const unsigned char* lb) {
+    // weights (B of the GEMM) are the MFMA A operand, so a lane ends up with runs of 4 consecutive n
+    if constexpr (kMfma32) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      Frag8 fa[TM], fb[TN];
-      const int slot = ks * 4 + (lane >> 4);
+      for (int ks = 0; ks < 4; ++ks) {          // 16 K elements per 32x32x16 MFMA: slot = 2*ks + (lane >> 5)
+        Frag8 fa[TM], fb[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i].u = *reinterpret_cast<const uint4*>(la + lds_slot(wr * WM + i * 16 + (lane & 15), slot));
+        for (int i = 0; i < TM; ++i) fa[i].u = *reinterpret_cast<const uint4*>(la + (fa_base ^ (ks * 32)) + i * 32 * kRowBytes);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j].u = *reinterpret_cast<const uint4*>(lb + lds_slot(wc * WN + j * 16 + (lane & 15), slot));
+        for (int j = 0; j < TN; ++j) fb[j].u = *reinterpret_cast<const uint4*>(lb + (fb_base ^ (ks * 32)) + j * 32 * kRowBytes);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)   // weights (B of the GEMM) are the MFMA A operand: lane gets 4 consecutive n
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j].v, fa[i].v, acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j].v, fa[i].v, acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {          // 32 K elements per 16x16x32 MFMA: slot = 4*ks + (lane >> 4)
+        Frag8 fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i].u = *reinterpret_cast<const uint4*>(la + (fa_base ^ (ks * 64)) + i * 16 * kRowBytes);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j].u = *reinterpret_cast<const uint4*>(lb + (fb_base ^ (ks * 64)) + j * 16 * kRowBytes);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j].v, fa[i].v, acc[i][j], 0, 0, 0);
+      }
     }
   };
+  // One K step, branch-free: multiply the tile in (ca, cb) while the registers of the next step are
+  // dequantised into (na, nb) and the loads of the step after that are issued.  The K index is clamped,
+  // so the last steps re-stage the final atom into a buffer nobody reads.
+  auto k_step = [&](int kt, const unsigned char* ca, const unsigned char* cb, unsigned char* na, unsigned char* nb) {
+    Staged ta[A_UNITS], tb[B_UNITS];
+#pragma unroll
+    for (int u = 0; u < A_UNITS; ++u) ta[u] = sa[u];
+#pragma unroll
+    for (int u = 0; u < B_UNITS; ++u) tb[u] = sb[u];
+    load_step(min(kt + 2, atoms_k - 1));          // in flight during this whole step
+    __builtin_amdgcn_sched_barrier(0);            // keep the loads at the top: hipcc otherwise sinks them to the barrier
+    mma_step(ca, cb);
+#pragma unroll
+    for (int u = 0; u < A_UNITS; ++u) stage_store(na, a_slot[u], ta[u], a_live[u]);
+#pragma unroll
+    for (int u = 0; u < B_UNITS; ++u) stage_store(nb, b_slot[u], tb[u], b_live[u]);
+    __syncthreads();
+  };
 
-  // ---- main loop: one barrier per K step, loads of step k+1 in flight during the MFMAs of step k
+  // ---- prologue: tile 0 into buffer 0, registers <- step 1
   load_step(0);
   store_step(lds_a0, lds_b0);
+  load_step(min(1, atoms_k - 1));
   __syncthreads();
-  for (int kt = 0; kt < atoms_k; ++kt) {
-    unsigned char* const ca = (kt & 1) ? lds_a1 : lds_a0;
-    unsigned char* const cb = (kt & 1) ? lds_b1 : lds_b0;
-    unsigned char* const na = (kt & 1) ? lds_a0 : lds_a1;
-    unsigned char* const nb = (kt & 1) ? lds_b0 : lds_b1;
-    const bool more = kt + 1 < atoms_k;
-    if (more) load_step(kt + 1);
-    mma_step(ca, cb);
-    if (more) store_step(na, nb);
-    __syncthreads();
+  int kt = 0;
+  for (; kt + 1 < atoms_k; kt += 2) {
+    k_step(kt, lds_a0, lds_b0, lds_a1, lds_b1);
+    k_step(kt + 1, lds_a1, lds_b1, lds_a0, lds_b0);
   }
+  if (kt < atoms_k) k_step(kt, lds_a0, lds_b0, lds_a1, lds_b1);
 
-  // ---- epilogue: lane holds D[m = .. + (lane & 15)][n = .. + 4*(lane >> 4) + r]
+  // ---- epilogue.  16x16 tiles: lane holds D[m = +(lane & 15)][n = +4*(lane >> 4) + r], r = 0..3.
+  //      32x32 tiles: lane holds D[m = +(lane & 31)][n = +8*g + 4*(lane >> 5) + r], g = 0..3, r = 0..3.
   const float alpha = p.alpha_host * (p.alpha_dev ? *p.alpha_dev : 1.0f);
   const bool vec_ok = (p.N & 3) == 0;
+  auto store4 = [&](int m, int n, float d0, float d1, float d2, float d3) {
+    if (m >= p.M || n >= p.N) return;
+    float d[4] = {alpha * d0, alpha * d1, alpha * d2, alpha * d3};
+    if (p.bias) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (n + r < p.N) d[r] += bf16_bits_to_f32(p.bias[n + r]);
+    }
+    if (p.out_dtype == ARCQ_OUT_F32) {
+      float* o = reinterpret_cast<float*>(p.D) + (size_t)m * p.N + n;
+      if (vec_ok) *reinterpret_cast<float4*>(o) = make_float4(d[0], d[1], d[2], d[3]);
+      else for (int r = 0; r < 4; ++r) if (n + r < p.N) o[r] = d[r];
+    } else {
+      uint16_t* o = reinterpret_cast<uint16_t*>(p.D) + (size_t)m * p.N + n;
+      if (vec_ok) *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3]));
+      else for (int r = 0; r < 4; ++r) if (n + r < p.N) o[r] = (uint16_t)f32_to_bf16_bits(d[r]);
+    }
+  };
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const int m = m0 + wr * WM + i * 16 + (lane & 15);
-    if (m >= p.M) continue;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wc * WN + j * 16 + 4 * (lane >> 4);
-      if (n >= p.N) continue;
-      float d[4];
+      if constexpr (kMfma32) {
+        const int m = m0 + wr * WM + i * 32 + (lane & 31);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        d[r] = alpha * acc[i][j][r];
-        if (p.bias && n + r < p.N) d[r] += bf16_bits_to_f32(p.bias[n + r]);
-      }
-      if (p.out_dtype == ARCQ_OUT_F32) {
-        float* o = reinterpret_cast<float*>(p.D) + (size_t)m * p.N + n;
-        if (vec_ok) *reinterpret_cast<float4*>(o) = make_float4(d[0], d[1], d[2], d[3]);
-        else for (int r = 0; r < 4; ++r) if (n + r < p.N) o[r] = d[r];
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + wc * WN + j * 32 + 8 * g + 4 * (lane >> 5);
+          store4(m, n, acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        }
       } else {
-        uint16_t* o = reinterpret_cast<uint16_t*>(p.D) + (size_t)m * p.N + n;
-        if (vec_ok) *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3]));
-        else for (int r = 0; r < 4; ++r) if (n + r < p.N) o[r] = (uint16_t)f32_to_bf16_bits(d[r]);
+        const int m = m0 + wr * WM + i * 16 + (lane & 15);
+        const int n = n0 + wc * WN + j * 16 + 4 * (lane >> 4);
+        store4(m, n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
       }
     }
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool kMfma32 = false>
 static int launch_tile(const GemmArgs& a, hipStream_t stream) {
   TileParams p;
   p.A = a.A; p.B = a.B; p.SFA = a.SFA; p.SFB = a.SFB; p.D = a.D;
@@ -210,7 +282,7 @@ static int launch_tile(const GemmArgs& a, hipStream_t stream) {
   p.tiles_m = (a.M + BM - 1) / BM;
   p.tiles_n = (a.N + BN - 1) / BN;
   const size_t lds = 2 * (size_t)(BM + BN) * kRowBytes;
-  auto kern = gemm_tile_kernel<BM, BN, WAVES_M, WAVES_N>;
+  auto kern = gemm_tile_kernel<BM, BN, WAVES_M, WAVES_N, kMfma32>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_gemm_nvfp4 (tile): cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
@@ -221,9 +293,31 @@ static int launch_tile(const GemmArgs& a, hipStream_t stream) {
   return ARCQ_OK;
 }
 
+// ARCQ_TILE_CFG (debug / tuning only): 0 = heuristic, 1 = 128x128 (4 waves), 2 = 256x256 (4 waves),
+// 3 = 256x256 (8 waves), 4 = 128x256 (4 waves)
+static int tile_cfg_override() {
+  static const int v = [] {
+    const char* e = getenv("ARCQ_TILE_CFG");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+
 int gemm_tile(const GemmArgs& a, hipStream_t stream) {
-  // small M: 64-row tiles keep more workgroups in flight; otherwise 128x128
-  if (a.M <= 64) return launch_tile<64, 128, 1, 4>(a, stream);
+  switch (tile_cfg_override()) {
+    case 1: return launch_tile<128, 128, 2, 2>(a, stream);
+    case 2: return launch_tile<256, 256, 2, 2>(a, stream);
+    case 3: return launch_tile<256, 256, 2, 4>(a, stream);
+    case 4: return launch_tile<128, 256, 2, 2>(a, stream);
+    case 5: return launch_tile<256, 256, 2, 4, true>(a, stream);
+    case 6: return launch_tile<128, 128, 2, 2, true>(a, stream);
+    default: break;
+  }
+  // 256x256 with 8 waves (one workgroup per CU, two waves per SIMD) once it yields enough tiles to fill the
+  // 256 CUs; 128x128 (two workgroups per CU) otherwise.  Measured on MI355X (tools/gemm_sweep.py):
+  // 4096^2: 1066 vs 762 TFLOP/s, 8192^2: 1347 vs 984.
+  const int64_t t256 = ((int64_t)(a.M + 255) / 256) * ((a.N + 255) / 256);
+  if (t256 >= 192) return launch_tile<256, 256, 2, 4>(a, stream);
   return launch_tile<128, 128, 2, 2>(a, stream);
 }
 
