@@ -7,8 +7,8 @@
 // cannot express a 3-mantissa-bit scale per 16; the exact contraction therefore runs on
 // v_mfma_f32_16x16x32_f16 after an in-register dequantisation:
 //     v_cvt_scalef32_pk_f16_fp4   (2 codes -> 2 fp16, probed on MI355X: the scale operand only
-//                                  contributes its exponent, so it is fed 1.0)
-//     v_pk_mul_f16                (x the fp16 copy of the ue4m3 scale; exact)
+//                                  contributes its exponent; it is fed 2^8, see sf_pair)
+//     v_pk_mul_f16                (x the ue4m3 scale re-read as fp16 bits; exact)
 // Products of two such fp16 values are exact in fp32, accumulation is the MFMA's fp32 chain.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -29,20 +29,28 @@ union Frag8 {        // 8 fp16 = one MFMA 16x16x32 operand fragment = 16 bytes
   uint4 u;
 };
 
-// ue4m3 byte -> fp16 pair (s, s).  4 significant bits, range [2^-9, 448]: exact in fp16.
+// ue4m3 byte -> fp16 pair (s', s') with s' = scale * 2^-8.  The e4m3 bit pattern shifted into the fp16 fields
+// (b << 7: exponent field = E, top mantissa bits = m) reads as (1 + m/8) * 2^(E-15) for E >= 1 and as the fp16
+// SUBNORMAL m * 2^-17 for E == 0 -- in both cases exactly scale * 2^-8 -- so the conversion is one shift and one
+// pack, no float math.  The missing 2^8 is supplied by the conversion below (its scale operand contributes
+// exactly its exponent).  fp16 denormals are preserved by v_pk_mul_f16 in the default kernel mode
+// (amdhsa_float_denorm_mode_16_64 = 3) and every product lands in the normal range again.
 __device__ __forceinline__ f16x2 sf_pair(uint32_t byte) {
-  _Float16 s = (_Float16)ue4m3_to_f32(byte);
-  f16x2 r = {s, s};
+  const uint32_t h = (byte & 0x7fu) << 7;
+  const uint32_t w = h | (h << 16);
+  f16x2 r;
+  __builtin_memcpy(&r, &w, 4);
   return r;
 }
 
-// 8 e2m1 codes (one dword, low nibble first) x scale -> 8 fp16.
+// 8 e2m1 codes (one dword, low nibble first) x scale -> 8 fp16:  (code * 2^8) * (scale * 2^-8), both factors and
+// the product exact in fp16.
 __device__ __forceinline__ Frag8 dequant8(uint32_t codes, f16x2 s2) {
   Frag8 f;
-  f.p[0] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(codes, 1.0f, 0) * s2;
-  f.p[1] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(codes, 1.0f, 1) * s2;
-  f.p[2] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(codes, 1.0f, 2) * s2;
-  f.p[3] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(codes, 1.0f, 3) * s2;
+  f.p[0] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(codes, 256.0f, 0) * s2;
+  f.p[1] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(codes, 256.0f, 1) * s2;
+  f.p[2] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(codes, 256.0f, 2) * s2;
+  f.p[3] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(codes, 256.0f, 3) * s2;
   return f;
 }
 

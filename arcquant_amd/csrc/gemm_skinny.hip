@@ -4,23 +4,23 @@
 // for the shapes where that kernel leaves 127/128 of its M tile empty ("decode").
 //
 // Roofline: bytes per launch = N*K*9/16 (packed B + scale bytes) + M*K*9/16 + M*N*2; everything else is
-// on-chip.  Design for that bound:
-//   * one workgroup (8 wave64) per 16 output columns = 16 rows of B; K is walked in slabs of 2048
-//     elements (1 KiB of packed codes per row)
-//   * every byte enters the CU through LDS-DMA (global_load_lds_dwordx4 / _dword): a wave-instruction
-//     moves one whole 1 KiB row slab, i.e. full 128-byte lines.  (The first version loaded B straight
-//     into the MFMA operand layout, 16 rows x 64 B per instruction; loads alone then took as long as
-//     the whole kernel.)  A 3-deep LDS ring keeps two slabs in flight behind the one being multiplied;
-//     waits are counted `s_waitcnt vmcnt(N)` + raw `s_barrier`, never vmcnt(0) inside the loop
-//   * LDS-DMA writes lane-linearly, so the bank-conflict swizzle is applied to the per-lane SOURCE
-//     address (16-byte unit ^ (row & 15)) and undone by the reader (cdna_hip_programming.md rule 21)
-//   * scale bytes are staged with 4-byte LDS-DMA pieces that pick exactly this tile's bytes out of the
-//     CUTLASS-swizzled layout (16 rows x 4 atoms = 256 useful bytes per instruction)
+// on-chip.  Measured floor for ONE short kernel that only reads that many bytes (tools/probe_stream.hip):
+// 9.6 MB -> 3.3 us, 33.5 MB -> 6.5 us.  Design for that bound:
+//   * persistent workgroups (8 wave64); a workgroup walks "items" = (tile of 16 weight rows, slab of 1024
+//     K elements).  Per item every thread fetches exactly ONE 16-byte unit of packed B with a plain
+//     global_load_dwordx4: a wave covers two 512-byte row segments (full lines; the first version loaded B
+//     straight into the MFMA operand layout, 16 rows x 64 B per instruction, and its loads alone took as
+//     long as the whole kernel).  A 6-deep REGISTER ring keeps six items in flight across tile boundaries,
+//     so HBM latency is paid once per workgroup, not once per tile
+//   * the packed bytes are transposed into the MFMA operand layout through a small double-buffered LDS
+//     image (padded rows: conflict-free), one barrier per item
+//   * a tile's 16 rows are {32j + 4t + i} of a 128-row super-tile: their scale bytes then fill whole
+//     64-byte lines of the CUTLASS-swizzled scale layout (4x fewer scale-line fetches than 16 consecutive
+//     rows), and a lane still ends up with 4 consecutive output columns
 //   * operands are dequantised in registers to fp16 (exact, gemm_common.hpp) and contracted on
-//     v_mfma_f32_16x16x32_f16 with the weights as the MFMA "A" operand, so a lane ends with 4
-//     consecutive output columns of one token (one 8-byte store)
+//     v_mfma_f32_16x16x32_f16 with the weights as the MFMA "A" operand
 //   * cross-wave reduction of the 16x16 fp32 tile through LDS; epilogue fused (alpha, optional bias,
-//     bf16 rounding); split-K over slabs (second pass) only when N/16 alone cannot fill the chip.
+//     bf16 rounding); split-K over slabs (second pass) only when the tiles alone cannot fill the chip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -44,6 +44,7 @@ struct SkinnyParams {
   int out_dtype;
   int tiles;              // ceil(N / 16)
   int slabs_per_split;
+  unsigned long long* trace;   // debug: per-workgroup wall-clock stamps (arcq_debug_set_trace), normally NULL
 };
 
 __device__ __forceinline__ void store_out4(const SkinnyParams& p, int m, int n, const float (&d)[4]) {
@@ -76,178 +77,206 @@ __device__ __forceinline__ void finish4(const SkinnyParams& p, int m, int n, con
   store_out4(p, m, n, d);
 }
 
-constexpr int kSlabK = 2048;                 // K elements per slab
-constexpr int kSlabBytes = kSlabK / 2;       // packed bytes per row per slab (= one LDS-DMA wave-instruction)
-constexpr int kSlabAtoms = kSlabK / 64;      // scale-factor atoms per slab
-constexpr int kSkWaves = 8;
-constexpr int kChunksPerWave = kSlabK / 128 / kSkWaves;   // 128-element MFMA chunks per wave per slab (= 2)
+// A workgroup of kWaves wave64 walks items of kWaves*128 K elements: one 16-byte unit per thread (loader role), one
+// 128-element MFMA chunk per wave (compute role).  kWaves = 16 (1024 threads, 2048-element items) halves the number
+// of barriers per byte and doubles the waves that hide each other's latencies; its fp16 A image only fits for M <= 8.
+template <int kWaves>
+struct SkinnyCfg {
+  static constexpr int kSlabK = kWaves * 128;            // K elements per item
+  static constexpr int kSlabBytes = kSlabK / 2;          // packed bytes per row per item
+  static constexpr int kUnits = kSlabBytes / 16;         // 16-byte units per row per item (= threads per row)
+  static constexpr int kSlabAtoms = kSlabK / 64;         // scale-factor atoms per item
+  // LDS per buffer: packed B image [16 rows][kSlabBytes + 16] and DEQUANTISED (fp16) A image [M + 1 tokens]
+  // [2*kSlabK + 16] (the extra token row stays zero and serves every MFMA column >= M)
+  static constexpr int kBStride = kSlabBytes + 16;
+  static constexpr int kBImg = 16 * kBStride;
+  static constexpr int kAStride = kSlabK * 2 + 16;
+  static constexpr int kRedBytes = kWaves * 64 * 4 * (int)sizeof(float);
+  static int lds_bytes(int M) { return 2 * (kBImg + (M + 1) * kAStride) + kRedBytes; }
+};
 
-// LDS stage: [B rows 16 KiB][A rows 16 KiB][SFB 2 KiB][SFA 2 KiB]
-constexpr int kStageB = 0;
-constexpr int kStageA = 16 * kSlabBytes;
-constexpr int kStageSFB = 2 * 16 * kSlabBytes;
-constexpr int kStageSFA = kStageSFB + kSlabAtoms * 16 * 4;
-constexpr int kStageBytes = kStageSFA + kSlabAtoms * 16 * 4;
-// LDS-DMA instructions per wave per slab: 2 B rows + 2 A rows + 1 SFB + 1 SFA.  FIXED: the waits are counted.
-constexpr int kGldsPerWavePerSlab = 6;
+struct ItemRegs {
+  uint4 b;             // loader role: this thread's 16-byte unit of packed B
+  uint4 a;             // loader role (token rows only): 16-byte unit of packed A
+  uint32_t sa;         // ... and the two scale bytes of that unit
+  uint32_t sb;         // compute role: this lane's 4 scale bytes (one atom) of B for its wave's chunk
+};
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void gbl_void_t;
+// At this size the kernel is INSTRUCTION-ISSUE bound, not only HBM bound (a 9.6 MB launch lasts ~3 us = ~7000
+// cycles per wave): every address below is carried incrementally and every mask is hoisted out of the item loop.
+template <int kWaves>
+__global__ __launch_bounds__(kWaves * 64, 4) void gemm_skinny_kernel(SkinnyParams p) {
+  using C = SkinnyCfg<kWaves>;
+  constexpr int kSlabK = C::kSlabK, kSlabBytes = C::kSlabBytes, kSlabAtoms = C::kSlabAtoms, kUnits = C::kUnits;
+  constexpr int kBStride = C::kBStride, kBImg = C::kBImg, kAStride = C::kAStride, kSkWaves = kWaves;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lds_buf = kBImg + (p.M + 1) * kAStride;
+  float* red = reinterpret_cast<float*>(smem + 2 * lds_buf);
 
-__device__ __forceinline__ void glds16(const void* src, void* lds_dst_wave_base) {
-  __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)lds_dst_wave_base, 16, 0, 0);
-}
-__device__ __forceinline__ void glds4(const void* src, void* lds_dst_wave_base) {
-  __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)lds_dst_wave_base, 4, 0, 0);
-}
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int q = lane >> 4;           // K quarter of the wave's 128-element chunk
+  const int rl = lane & 15;          // MFMA row index (weight row rho) / token index
+  const int ld_rho = tid / kUnits;   // loader role: row of the tile (B) / token (A) ...
+  const int ld_u = tid % kUnits;     // ... and 16-byte unit (32 elements) within the row segment of this item
 
-template <int kStages>
-__global__ __launch_bounds__(kSkWaves * 64) void gemm_skinny_kernel(SkinnyParams p) {
-  static_assert(kStages >= 2 && kStages <= 4, "ring depth");
-  
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [kStages][kStageBytes] + reduction
-  float* red = reinterpret_cast<float*>(smem + kStages * kStageBytes);   // [kSkWaves][64][4]
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int q = lane >> 4;           // K quarter of a 128-element chunk
-  const int rl = lane & 15;          // weight row within the tile / token index
-
-  // XCD-aware tile order: the 8 tiles of a 128-row scale-factor super-tile share 64-byte lines of SFB, keep
-  // them on one XCD (blocks are dealt round-robin over the 8 XCDs); bijective for any tile count.
-  int tile = blockIdx.x;
-  {
-    const int q8 = p.tiles >> 3, r8 = p.tiles & 7, x = tile & 7, j = tile >> 3;
-    tile = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + j;
-  }
-  const int n0 = tile * 16;
   const int atoms_k = p.K >> 6;
-  const int half_k = p.K >> 1;
-  const int nslabs_total = (p.K + kSlabK - 1) / kSlabK;
+  const uint32_t half_k = (uint32_t)p.K >> 1;
   const int slab_begin = blockIdx.y * p.slabs_per_split;
-  const int slab_end = min(nslabs_total, slab_begin + p.slabs_per_split);
-  const int nslabs = slab_end - slab_begin;
+  const int nslabs = min((p.K + kSlabK - 1) / kSlabK, slab_begin + p.slabs_per_split) - slab_begin;
+  const int G = gridDim.x;
+  const int my_tiles = (p.tiles - (int)blockIdx.x + G - 1) / G;
+  const int nitems = my_tiles * nslabs;
+  const bool m_ok = rl < p.M;
+  const bool a_loader = ld_rho < p.M;
 
-  const int n = n0 + rl, m = rl;
-  const bool n_ok = n < p.N, m_ok = m < p.M;
+  unsigned long long* tr = p.trace ? p.trace + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+  if (tr && tid == 0) tr[0] = wall_clock64();
 
-  // ---- LDS-DMA sources of this wave (loop invariant parts).  Addresses are clamped into the buffers;
-  //      whatever lands beyond the valid K range / row range is never read or is masked via its scale.
-  const int brow0 = min(n0 + wave, p.N - 1), brow1 = min(n0 + wave + 8, p.N - 1);
-  // A rows beyond M are not fetched at all (with M = 1 they would be 15 redundant copies of row 0 from one
-  // hot L2 line); the number of LDS-DMA ops this wave issues per slab is therefore wave-dependent (4..6)
-  const bool a0_on = wave < p.M, a1_on = wave + 8 < p.M;
-  const int per_slab = 4 + (a0_on ? 1 : 0) + (a1_on ? 1 : 0);
-  const int arow0 = min(wave, p.M - 1), arow1 = min(wave + 8, p.M - 1);
-  const uint8_t* bsrc0 = p.B + (size_t)brow0 * half_k;
-  const uint8_t* bsrc1 = p.B + (size_t)brow1 * half_k;
-  const uint8_t* asrc0 = p.A + (size_t)arow0 * half_k;
-  const uint8_t* asrc1 = p.A + (size_t)arow1 * half_k;
-  // source 16-byte unit of this lane within a slab row: lane ^ (tile row & 15)   (involution, undone by the reader)
-  const int unit0 = (lane ^ (wave & 15)) * 16, unit1 = (lane ^ ((wave + 8) & 15)) * 16;
-  // scale bytes: lane (row rl, atom wave*4 + q of the slab) fetches its 4-byte group
-  const uint8_t* sfb_src = p.SFB + sf_atom_offset(min(n, p.N - 1), 0, atoms_k);
-  const uint8_t* sfa_src = p.SFA + sf_atom_offset(min(m, p.M - 1), 0, atoms_k);
+  // A tile's 16 rows are {128*T + 32*j + 4*t + i}: rho = 4j + i
+  const int ld_rowpart = (ld_rho >> 2) * 32 + (ld_rho & 3);
+  const int cm_rowpart = (rl >> 2) * 32 + (rl & 3);
+  const uint32_t k_first = (uint32_t)slab_begin * kSlabBytes + ld_u * 16;      // byte offset of this thread's unit in slab 0
+  const uint32_t k_last = half_k - 16u;                                        // clamp for the partial tail slab
+  const uint32_t sfb_lane = (rl & 3) * 16 + (rl >> 2) * 4 + (2 * wave + (q >> 1)) * 512 + (uint32_t)slab_begin * kSlabAtoms * 512u;
+  const uint32_t sfb_small = (rl & 3) * 16 + (rl >> 2) * 4;
+  const uint32_t sfa_first = (uint32_t)ld_rho * 16 + ((uint32_t)slab_begin * kSlabAtoms + (ld_u >> 1)) * 512u + (ld_u & 1) * 2;
+  const uint32_t sfa_last = (uint32_t)ld_rho * 16 + (uint32_t)(atoms_k - 1) * 512u + (ld_u & 1) * 2;
 
-  auto issue_slab = [&](int slab, int stage) {
-    unsigned char* st = smem + stage * kStageBytes;
-    const int kbyte = slab * kSlabBytes;
-    const int lim = half_k - 16 - kbyte;                      // last valid 16-byte unit of the row in this slab
-    const int o0 = kbyte + min(unit0, lim), o1 = kbyte + min(unit1, lim);
-    glds16(bsrc0 + o0, st + kStageB + wave * kSlabBytes);
-    glds16(bsrc1 + o1, st + kStageB + (wave + 8) * kSlabBytes);
-    if (a0_on) glds16(asrc0 + o0, st + kStageA + wave * kSlabBytes);
-    if (a1_on) glds16(asrc1 + o1, st + kStageA + (wave + 8) * kSlabBytes);
-    const int atom = min(slab * kSlabAtoms + wave * 4 + q, atoms_k - 1);
-    glds4(sfb_src + (size_t)atom * 512, st + kStageSFB + wave * 256);    // LDS dword index = (wave*4 + q)*16 + rl
-    glds4(sfa_src + (size_t)atom * 512, st + kStageSFA + wave * 256);
+  // ---- issue side state (runs kRing items ahead of the compute side); all offsets are carried incrementally
+  int iss_tile = blockIdx.x, iss_slab = 0, issued = 0;
+  uint32_t b_row = 0, sfb_row = 0, sfb_rowmax = 0;       // per-tile parts
+  auto issue_tile_setup = [&]() {
+    const int tile_part = (iss_tile >> 3) * 128 + (iss_tile & 7) * 4;
+    b_row = (uint32_t)min(tile_part + ld_rowpart, p.N - 1) * half_k;
+    sfb_row = (uint32_t)(iss_tile >> 3) * atoms_k * 512u + (iss_tile & 7) * 64u;
+    sfb_rowmax = sfb_row + (uint32_t)(atoms_k - 1) * 512u + sfb_small;
+  };
+  issue_tile_setup();
+  uint32_t k_cur = k_first, sfb_cur = sfb_lane, sfa_cur = sfa_first;
+  const uint32_t a_row = (uint32_t)ld_rho * half_k;
+  auto issue_next = [&](ItemRegs& r) {
+    if (issued < nitems) {                                     // wave-uniform
+      const uint32_t koff = min(k_cur, k_last);
+      r.b = *reinterpret_cast<const uint4*>(p.B + (size_t)(b_row + koff));
+      r.sb = *reinterpret_cast<const uint32_t*>(p.SFB + (size_t)min(sfb_row + sfb_cur, sfb_rowmax));
+      if (a_loader) {
+        r.a = *reinterpret_cast<const uint4*>(p.A + (size_t)(a_row + koff));
+        r.sa = *reinterpret_cast<const uint16_t*>(p.SFA + (size_t)min(sfa_cur, sfa_last));
+      }
+      ++issued;
+      k_cur += kSlabBytes; sfb_cur += kSlabAtoms * 512u; sfa_cur += kSlabAtoms * 512u;
+      if (++iss_slab == nslabs) {
+        iss_slab = 0; iss_tile += G;
+        k_cur = k_first; sfb_cur = sfb_lane; sfa_cur = sfa_first;
+        issue_tile_setup();
+      }
+    }
   };
 
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_void_t*)smem;   // LDS byte address of the dynamic region
+  // Code size matters as much as instruction count here: every launch starts with a cold instruction cache and
+  // most of this kernel runs exactly once per workgroup, so the item loop is ROLLED (the register ring advances
+  // by moves instead of by unrolling) and the per-tile epilogue exists once.
+  ItemRegs r0, r1, r2;
+  r0.b = r0.a = r1.b = r1.a = r2.b = r2.a = make_uint4(0, 0, 0, 0);
+  r0.sb = r0.sa = r1.sb = r1.sa = r2.sb = r2.sa = 0;
+  issue_next(r0);
+  issue_next(r1);
+  issue_next(r2);
+  if (tr && tid == 0) tr[1] = wall_clock64();
 
-  // ---- prologue: fill the ring
+  // the spare token row of both A images stays zero; MFMA columns >= M read it
+  if (ld_rho == 0) {
 #pragma unroll
-  for (int s = 0; s < kStages - 1; ++s)
-    if (s < nslabs) issue_slab(slab_begin + s, s);
-
-  for (int s = 0; s < nslabs; ++s) {
-    // wait for this wave's pieces of slab s: everything it issued later may stay in flight
-    const int later = min(kStages - 2, nslabs - 1 - s);
-    switch (later * per_slab) {        // wave-uniform; the immediate must be a literal
-      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-      case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-    __builtin_amdgcn_s_barrier();      // all pieces of slab s have landed; every wave is done reading slab s-1
-    if (s + kStages - 1 < nslabs) issue_slab(slab_begin + s + kStages - 1, (s + kStages - 1) % kStages);
-
-    const unsigned char* st = smem + (s % kStages) * kStageBytes;
-    const int slab = slab_begin + s;
+    for (int b2 = 0; b2 < 2; ++b2)
 #pragma unroll
-    for (int cc = 0; cc < kChunksPerWave; ++cc) {
-      const int c = wave * kChunksPerWave + cc;                 // chunk within the slab: bytes [64c, 64c+64) of each row
-      const int atom_l = 2 * c + (q >> 1);                      // this lane's atom within the slab
-      const bool live = slab * kSlabAtoms + atom_l < atoms_k;
-      const int unit = (4 * c + q) ^ rl;                        // undo the source swizzle
-      // The LDS reads are inline asm: hipcc's waitcnt pass cannot tell that a ds_read of stage s does not alias
-      // the LDS-DMA writes in flight to the other stages and would drain them with vmcnt(0) (seen in the .s),
-      // serialising the ring.  Ordering is ours: the counted vmcnt + barrier above (cdna_hip_programming.md 5.7).
-      u32x4 bq, aq;
-      uint32_t bs, as;
-      const uint32_t frag_addr = (uint32_t)(uintptr_t)(st - smem) + kStageB + rl * kSlabBytes + unit * 16;
-      const uint32_t sf_addr = (uint32_t)(uintptr_t)(st - smem) + kStageSFB + (atom_l * 16 + rl) * 4;
-      asm volatile(
-          "ds_read_b128 %0, %4\n\t"
-          "ds_read_b128 %1, %4 offset:%c6\n\t"
-          "ds_read_b32 %2, %5\n\t"
-          "ds_read_b32 %3, %5 offset:%c7\n\t"
-          "s_waitcnt lgkmcnt(0)"
-          : "=&v"(bq), "=&v"(aq), "=&v"(bs), "=&v"(as)
-          : "v"(frag_addr + lds_base), "v"(sf_addr + lds_base), "i"(kStageA - kStageB), "i"(kStageSFA - kStageSFB));
+      for (int c = 0; c < 4; ++c)
+        *reinterpret_cast<uint4*>(smem + b2 * lds_buf + kBImg + p.M * kAStride + ld_u * 64 + c * 16) = make_uint4(0, 0, 0, 0);
+  }
+
+  const int wrb_off = ld_rho * kBStride + ld_u * 16;                  // loader role: packed B unit
+  const int wra_off = kBImg + ld_rho * kAStride + ld_u * 64;          // loader role: 32 dequantised A values (64 B)
+  const int wra_swz = (ld_u >> 1) & 3;                                // 16-byte chunk c is stored at position c ^ swz
+  const int rdb_off = rl * kBStride + (4 * wave + q) * 16;            // compute role: this lane's packed B fragment
+  const int rda_off = kBImg + min(rl, p.M) * kAStride + (4 * wave + q) * 64;   // ... and its four fp16 A fragments
+  const int rda_swz = (2 * wave + (q >> 1)) & 3;
+  const int sh = (q & 1) * 16;                                        // which two of the atom's four B scale bytes
+  const int lane_atom = slab_begin * kSlabAtoms + 2 * wave + (q >> 1);   // compute role: atom of slab 0
+  const int ld_atom = slab_begin * kSlabAtoms + (ld_u >> 1);             // loader role (A): atom of slab 0
+  int parity = 0;
+  bool first = true;
+
+#pragma unroll 1
+  for (int cur_tile = blockIdx.x; cur_tile < p.tiles; cur_tile += G) {
+    const bool n_ok = (cur_tile >> 3) * 128 + (cur_tile & 7) * 4 + cm_rowpart < p.N;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int cur_slab = 0; cur_slab < nslabs; ++cur_slab) {
+      unsigned char* buf = smem + parity * lds_buf;
+      parity ^= 1;
+      *reinterpret_cast<uint4*>(buf + wrb_off) = r0.b;
+      if (a_loader) {
+        // dequantise this thread's 32 activations once for the whole workgroup (cost scales with M, not 16)
+        const uint32_t sa = ld_atom + cur_slab * kSlabAtoms < atoms_k ? r0.sa : 0u;
+        const f16x2 s0 = sf_pair(sa & 0xffu), s1 = sf_pair((sa >> 8) & 0xffu);
+        Frag8 f0 = dequant8(r0.a.x, s0), f1 = dequant8(r0.a.y, s0), f2 = dequant8(r0.a.z, s1), f3 = dequant8(r0.a.w, s1);
+        *reinterpret_cast<uint4*>(buf + wra_off + ((0 ^ wra_swz) << 4)) = f0.u;
+        *reinterpret_cast<uint4*>(buf + wra_off + ((1 ^ wra_swz) << 4)) = f1.u;
+        *reinterpret_cast<uint4*>(buf + wra_off + ((2 ^ wra_swz) << 4)) = f2.u;
+        *reinterpret_cast<uint4*>(buf + wra_off + ((3 ^ wra_swz) << 4)) = f3.u;
+      }
+      uint32_t bs = r0.sb;
+      r0 = r1;                                                 // advance the ring ...
+      r1 = r2;
+      issue_next(r2);                                          // ... and refill its tail: kRing items ahead
+      __syncthreads();
+      if (tr && tid == 0 && first) { tr[2] = wall_clock64(); first = false; }
+      const bool live = lane_atom + cur_slab * kSlabAtoms < atoms_k;   // false only in the partial tail slab
       bs = (live && n_ok) ? bs : 0u;
-      as = (live && m_ok) ? as : 0u;
-      const int sh = (q & 1) * 16;                              // which two of the atom's four scale bytes
+      const uint4 bq = *reinterpret_cast<const uint4*>(buf + rdb_off);
+      Frag8 a0, a1, a2, a3;
+      a0.u = *reinterpret_cast<const uint4*>(buf + rda_off + ((0 ^ rda_swz) << 4));
+      a1.u = *reinterpret_cast<const uint4*>(buf + rda_off + ((1 ^ rda_swz) << 4));
+      a2.u = *reinterpret_cast<const uint4*>(buf + rda_off + ((2 ^ rda_swz) << 4));
+      a3.u = *reinterpret_cast<const uint4*>(buf + rda_off + ((3 ^ rda_swz) << 4));
       const f16x2 sb0 = sf_pair((bs >> sh) & 0xffu), sb1 = sf_pair((bs >> (sh + 8)) & 0xffu);
-      const f16x2 sa0 = sf_pair((as >> sh) & 0xffu), sa1 = sf_pair((as >> (sh + 8)) & 0xffu);
       Frag8 b0 = dequant8(bq.x, sb0), b1 = dequant8(bq.y, sb0), b2 = dequant8(bq.z, sb1), b3 = dequant8(bq.w, sb1);
-      Frag8 a0 = dequant8(aq.x, sa0), a1 = dequant8(aq.y, sa0), a2 = dequant8(aq.z, sa1), a3 = dequant8(aq.w, sa1);
-      // weights are the MFMA A operand (rows i = n), activations the B operand (cols j = m)
+      // weights are the MFMA A operand (rows i = rho), activations the B operand (cols j = token)
       acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0.v, a0.v, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1.v, a1.v, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b2.v, a2.v, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b3.v, a3.v, acc, 0, 0, 0);
     }
-  }
+    if (tr && tid == 0 && cur_tile + G >= p.tiles) tr[3] = wall_clock64();
 
-  // ---- cross-wave reduction; lane holds C[n = n0 + 4q + r][m = rl]
+    // ---- tile done: cross-wave reduction; lane holds C[rho = 4q + r][token = rl]
 #pragma unroll
-  for (int r = 0; r < 4; ++r) red[(wave * 64 + lane) * 4 + r] = acc[r];
-  __syncthreads();
-  if (wave == 0) {
-    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < 4; ++r) red[(wave * 64 + lane) * 4 + r] = acc[r];
+    __syncthreads();
+    if (wave == 0) {
+      float sum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int w = 0; w < kSkWaves; ++w) {
-      const float4 v = *reinterpret_cast<const float4*>(red + (w * 64 + lane) * 4);
-      sum[0] += v.x; sum[1] += v.y; sum[2] += v.z; sum[3] += v.w;
-    }
-    if (m_ok) {
-      const int nn = n0 + 4 * q;
-      if (gridDim.y == 1) {
-        finish4(p, m, nn, sum);
-      } else {
-        float* o = p.partial + ((size_t)blockIdx.y * p.M + m) * p.N + nn;
-        for (int r = 0; r < 4; ++r) if (nn + r < p.N) o[r] = sum[r];
+      for (int w = 0; w < kSkWaves; ++w) {
+        const float4 v = *reinterpret_cast<const float4*>(red + (w * 64 + lane) * 4);
+        sum[0] += v.x; sum[1] += v.y; sum[2] += v.z; sum[3] += v.w;
+      }
+      const int nn = (cur_tile >> 3) * 128 + (cur_tile & 7) * 4 + q * 32;   // rho = 4q + r -> 4 consecutive columns
+      if (m_ok && nn < p.N) {
+        if (gridDim.y == 1) {
+          finish4(p, rl, nn, sum);
+        } else {
+          float* o = p.partial + ((size_t)blockIdx.y * p.M + rl) * p.N + nn;
+          for (int r = 0; r < 4; ++r) if (nn + r < p.N) o[r] = sum[r];
+        }
       }
     }
+    if (tr && tid == 0 && cur_tile + G >= p.tiles) tr[4] = wall_clock64();
+    // `red` is next written after at least one more __syncthreads (the next tile's first item), so no barrier here
   }
 }
+
+void* g_trace_buf = nullptr;   // set by arcq_debug_set_trace
 
 // second pass of split-K: D[m,n] = epilogue(sum_s partial[s,m,n]) in a fixed order (deterministic)
 __global__ __launch_bounds__(256) void splitk_finish_kernel(SkinnyParams p, int splitk) {
@@ -263,10 +292,10 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(SkinnyParams p, int 
   finish4(p, m, n, s);
 }
 
-// split-K (over 2048-element slabs) only when the N tiles alone leave most CUs idle
-static void choose_split(int64_t N, int64_t K, int* splitk, int* slabs_per_split) {
-  const int64_t tiles = (N + 15) / 16;
-  const int nslabs = (int)((K + kSlabK - 1) / kSlabK);
+// split-K (over whole items) only when the tiles alone leave most CUs idle
+static void choose_split(int64_t N, int64_t K, int slab_k, int* splitk, int* slabs_per_split) {
+  const int64_t tiles = ((N + 127) / 128) * 8;
+  const int nslabs = (int)((K + slab_k - 1) / slab_k);
   int s = 1;
   if ((N % 4) == 0) {
     while (tiles * s < 192 && s * 2 <= nslabs && s < 16) s *= 2;
@@ -277,41 +306,64 @@ static void choose_split(int64_t N, int64_t K, int* splitk, int* slabs_per_split
   *slabs_per_split = per;
 }
 
+// 16 waves (1024 threads, one workgroup per CU) while one workgroup per CU covers all tiles and the fp16 A image
+// fits (M <= 8); 8 waves (two workgroups per CU) otherwise.  Measured on MI355X (tools/decode_bench.py, M = 1..4):
+// N=4096 KQ=4096: 16 waves 7.1 us vs 8 waves 7.2 us;  N=14336 KQ=4096: 8 waves 15.3 us vs 16 waves 19.2 us.
+static int skinny_waves(int64_t M, int64_t N) {
+  static const int forced = getenv("ARCQ_SKINNY_WAVES") ? atoi(getenv("ARCQ_SKINNY_WAVES")) : 0;
+  if (forced == 8 || (forced == 16 && M <= 8)) return forced;
+  const int64_t tiles = ((N + 127) / 128) * 8;
+  return (M <= 8 && tiles <= 256) ? 16 : 8;
+}
+
 int64_t gemm_skinny_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   int s, per;
-  choose_split(N, K, &s, &per);
+  choose_split(N, K, skinny_waves(M, N) * 128, &s, &per);
   return s > 1 ? (int64_t)s * M * N * (int64_t)sizeof(float) : 0;
 }
 
+template <int kWaves>
+static int launch_skinny(const SkinnyParams& p, int splitk, hipStream_t stream) {
+  using C = SkinnyCfg<kWaves>;
+  const int lds = C::lds_bytes(p.M);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel<kWaves>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       C::lds_bytes(kWaves == 16 ? 8 : 16));
+    if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_gemm_nvfp4 (skinny): cannot reserve LDS: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  // persistent workgroups, each walks tiles blockIdx.x, +grid, ...; 8-wave groups fit two per CU
+  static const int forced_grid = getenv("ARCQ_SKINNY_GRID") ? atoi(getenv("ARCQ_SKINNY_GRID")) : 0;
+  const int max_wg = forced_grid > 0 ? forced_grid : (kWaves == 16 ? 256 : 512);
+  const int per_split = max_wg / splitk > 0 ? max_wg / splitk : 1;
+  const int gx = p.tiles < per_split ? p.tiles : per_split;
+  hipLaunchKernelGGL(gemm_skinny_kernel<kWaves>, dim3((unsigned)gx, (unsigned)splitk), dim3(kWaves * 64), lds, stream, p);
+  return ARCQ_OK;
+}
+
 int gemm_skinny(const GemmArgs& a, hipStream_t stream) {
+  const int waves = skinny_waves(a.M, a.N);
   int splitk, per;
-  choose_split(a.N, a.K, &splitk, &per);
+  choose_split(a.N, a.K, waves * 128, &splitk, &per);
   SkinnyParams p;
   p.A = a.A; p.B = a.B; p.SFA = a.SFA; p.SFB = a.SFB; p.D = a.D;
   p.partial = reinterpret_cast<float*>(a.workspace);
   p.alpha_dev = a.alpha_dev; p.bias = a.bias;
   p.M = a.M; p.N = a.N; p.K = a.K; p.alpha_host = a.alpha_host; p.out_dtype = a.out_dtype;
-  p.tiles = (a.N + 15) / 16;
+  p.tiles = ((a.N + 127) / 128) * 8;
   p.slabs_per_split = per;
+  p.trace = reinterpret_cast<unsigned long long*>(g_trace_buf);
   if (splitk > 1) {
     const int64_t need = (int64_t)splitk * a.M * a.N * (int64_t)sizeof(float);
     if (!a.workspace || a.workspace_bytes < need)
       return fail(ARCQ_ERR_WORKSPACE, "arcq_gemm_nvfp4: split-K needs %lld B of workspace, got %lld", (long long)need,
                   (long long)a.workspace_bytes);
   }
-  const dim3 grid((unsigned)p.tiles, (unsigned)splitk);
-  // one workgroup per CU fits a 4-deep ring (152 KiB: K <= 6144 is then entirely in flight at once); with more tiles than CUs use a 2-deep ring so that two
-  // workgroups share a CU and cover each other's start-up latency
-  const bool deep = (int64_t)p.tiles * splitk <= 320;
-  const size_t lds = (size_t)(deep ? 4 : 2) * kStageBytes + kSkWaves * 64 * 4 * sizeof(float);
-  auto kern = deep ? gemm_skinny_kernel<4> : gemm_skinny_kernel<2>;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[deep ? 1 : 0]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_gemm_nvfp4 (skinny): cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-    attr_set[deep ? 1 : 0] = true;
-  }
-  hipLaunchKernelGGL(kern, grid, dim3(kSkWaves * 64), lds, stream, p);
+  if ((int64_t)a.N * (a.K / 2) >= ((int64_t)1 << 32) || (int64_t)((a.N + 127) / 128) * 128 * (a.K / 16) >= ((int64_t)1 << 32))
+    return fail(ARCQ_ERR_UNSUPPORTED, "arcq_gemm_nvfp4 (skinny): operand larger than 4 GiB");
+  const int rc = waves == 16 ? launch_skinny<16>(p, splitk, stream) : launch_skinny<8>(p, splitk, stream);
+  if (rc != ARCQ_OK) return rc;
   if (splitk > 1) {
     const int64_t quads = ((int64_t)a.M * a.N + 3) / 4;
     hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p, splitk);

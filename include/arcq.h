@@ -111,6 +111,11 @@ int arcq_gemm_nvfp4(const uint8_t *A, const uint8_t *B, const uint8_t *SFA, cons
 /* scale_out[0] = max|x| / (448*6) as fp32; x is bf16 [n]. */
 int arcq_absmax_scale(const void *X, int64_t n, float *scale_out, void *stream);
 
+/* ---- debug (tuning only): the decode GEMM writes 8 x u64 wall-clock (100 MHz) stamps per workgroup into
+ *      dev_buf while it is non-NULL: [0] start, [1] prefetch issued, [2] first item landed, [3] last item
+ *      multiplied, [4] last tile stored. */
+int arcq_debug_set_trace(void *dev_buf);
+
 #ifdef __cplusplus
 }
 #endif
