@@ -1,0 +1,188 @@
+"""Synthetic-weight decode / prefill harness for the ARC-NVFP4 hot path.
+
+Reproduces the CALLER side of the reference's latency benchmark -- benchmarks/modeling_arc.py (decoder layer
+structure :279-310, MLP :109-111, RMSNorm+quantise :211-228, QLinearLayer :19-56) and
+benchmarks/benchmark_e2e_arc.py (MODEL_CFGS :26-77, protocol :84-115) -- on top of ``arcquant_amd.agemm``:
+
+    per layer:  rmsnorm_quantize_x -> q/k/v GEMMs -> attention -> reorder_quantize_x -> o GEMM -> +residual
+                rmsnorm_quantize_x -> gate/up GEMMs -> silu*mul -> reorder_quantize_x -> down GEMM -> +residual
+
+Differences from the reference files (which cannot run here: they need the `flashinfer` package and
+transformers-4.44 internals): attention is torch SDPA over a dense bf16 KV cache instead of flashinfer paged KV;
+weights are random-init and quantised once with ``agemm.reorder_quantize_w`` (the reference uses all-zero codes);
+``select_num`` is 64 for every linear (the calibration artefact is not in the repo); the decode step is captured
+in a HIP graph, so host launch overhead does not pace the GPU (every arcquant_amd launch is stream-ordered and
+allocation-free apart from torch's caching allocator).
+"""
+from __future__ import annotations
+
+import dataclasses
+import time
+
+import torch
+import torch.nn.functional as F
+
+from . import agemm
+
+
+@dataclasses.dataclass
+class ModelConfig:
+    name: str
+    num_layers: int
+    num_heads: int
+    hidden_size: int
+    intermediate_size: int
+    vocab_size: int = 32000          # LlamaConfig default used by benchmarks/modeling_arc.py:431
+    select_num: int = 64
+    eps: float = 1e-6
+
+
+# benchmarks/benchmark_e2e_arc.py:26-77
+MODEL_CFGS = {
+    "qwen2.5-7b": ModelConfig("qwen2.5-7b", 28, 28, 3584, 18944),
+    "llama-2-7b": ModelConfig("llama-2-7b", 32, 32, 4096, 11008),
+    "llama-3.1-8b": ModelConfig("llama-3.1-8b", 32, 32, 4096, 14336),
+    "qwen2.5-14b": ModelConfig("qwen2.5-14b", 48, 40, 5120, 13824),
+    "qwen2.5-32b": ModelConfig("qwen2.5-32b", 64, 40, 5120, 27648),
+}
+
+
+class QLinear:
+    """Quantised weight of one linear (random init), model/qLinearLayer.py:30-62 without the nn.Module shell."""
+
+    def __init__(self, in_f, out_f, select_num, device, gen):
+        w = (torch.randn(out_f, in_f, generator=gen, device=device, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+        self.idx = torch.arange(in_f, dtype=torch.int16, device=device)
+        scale = torch.max(w).float() / (448.0 * 6.0)
+        self.W, self.SFW = agemm.reorder_quantize_w((w / scale).contiguous(), self.idx, select_num)
+        self.scale = scale.reshape(1)
+        self.in_f, self.out_f, self.KE = in_f, out_f, select_num
+
+    def bytes(self):
+        return self.W.numel() + self.out_f * (self.in_f + self.KE) // 16
+
+
+class DecoderModel:
+    def __init__(self, cfg: ModelConfig, batch: int, max_len: int, device):
+        self.cfg, self.device, self.batch, self.max_len = cfg, device, batch, max_len
+        g = torch.Generator(device=device).manual_seed(0)
+        h, it, ke = cfg.hidden_size, cfg.intermediate_size, cfg.select_num
+        self.layers = []
+        for _ in range(cfg.num_layers):
+            self.layers.append(dict(
+                ln1=torch.ones(h, dtype=torch.bfloat16, device=device), ln2=torch.ones(h, dtype=torch.bfloat16, device=device),
+                q=QLinear(h, h, ke, device, g), k=QLinear(h, h, ke, device, g), v=QLinear(h, h, ke, device, g),
+                o=QLinear(h, h, ke, device, g), gate=QLinear(h, it, ke, device, g), up=QLinear(h, it, ke, device, g),
+                down=QLinear(it, h, ke, device, g),
+                kc=torch.zeros(batch, cfg.num_heads, max_len, h // cfg.num_heads, dtype=torch.bfloat16, device=device),
+                vc=torch.zeros(batch, cfg.num_heads, max_len, h // cfg.num_heads, dtype=torch.bfloat16, device=device)))
+        self.idx_h = torch.arange(h, dtype=torch.int16, device=device)
+        self.idx_i = torch.arange(it, dtype=torch.int16, device=device)
+        self.norm = torch.ones(h, dtype=torch.bfloat16, device=device)
+        self.lm_head = (torch.randn(cfg.vocab_size, h, generator=g, device=device) * 0.02).to(torch.bfloat16)
+        self.embed = (torch.randn(cfg.vocab_size, h, generator=g, device=device) * 0.02).to(torch.bfloat16)
+        self.one = torch.ones(1, dtype=torch.float32, device=device)
+
+    def weight_bytes(self):
+        per_layer = sum(self.layers[0][k].bytes() for k in ("q", "k", "v", "o", "gate", "up", "down"))
+        return per_layer * self.cfg.num_layers + self.lm_head.numel() * 2
+
+    @staticmethod
+    def _quant_x(x, idx, ke):
+        # model/qLlamaLayer.py:73-77 semantics, with the per-tensor scale kept on the device
+        scale = agemm.absmax_scale(x)
+        qx, sfx = agemm.reorder_quantize_x((x / scale).contiguous(), idx, ke)
+        return qx, sfx, scale
+
+    def forward(self, tokens: torch.Tensor, pos: int):
+        """tokens [batch, q_len] int64; appends K/V at [pos, pos+q_len) and attends over [0, pos+q_len)."""
+        cfg = self.cfg
+        bsz, q_len = tokens.shape
+        nh, hd = cfg.num_heads, cfg.hidden_size // cfg.num_heads
+        hcur = self.embed[tokens].reshape(bsz * q_len, cfg.hidden_size)
+        for L in self.layers:
+            A, SFA = agemm.rmsnorm_quantize_x(hcur, L["ln1"], cfg.eps, self.idx_h, cfg.select_num)
+            q = agemm.matmul(A, L["q"].W, SFA, L["q"].SFW, L["q"].scale)
+            k = agemm.matmul(A, L["k"].W, SFA, L["k"].SFW, L["k"].scale)
+            v = agemm.matmul(A, L["v"].W, SFA, L["v"].SFW, L["v"].scale)
+            q = q.view(bsz, q_len, nh, hd).transpose(1, 2)
+            L["kc"][:, :, pos:pos + q_len] = k.view(bsz, q_len, nh, hd).transpose(1, 2)
+            L["vc"][:, :, pos:pos + q_len] = v.view(bsz, q_len, nh, hd).transpose(1, 2)
+            att = F.scaled_dot_product_attention(q, L["kc"][:, :, :pos + q_len], L["vc"][:, :, :pos + q_len], is_causal=(q_len > 1 and pos == 0))
+            att = att.transpose(1, 2).reshape(bsz * q_len, cfg.hidden_size)
+            qa, sfa, sa = self._quant_x(att, self.idx_h, cfg.select_num)
+            hcur = hcur + agemm.matmul(qa, L["o"].W, sfa, L["o"].SFW, sa * L["o"].scale)
+            A, SFA = agemm.rmsnorm_quantize_x(hcur, L["ln2"], cfg.eps, self.idx_h, cfg.select_num)
+            gate = agemm.matmul(A, L["gate"].W, SFA, L["gate"].SFW, L["gate"].scale)
+            up = agemm.matmul(A, L["up"].W, SFA, L["up"].SFW, L["up"].scale)
+            act = F.silu(gate) * up
+            qa, sfa, sa = self._quant_x(act, self.idx_i, cfg.select_num)
+            hcur = hcur + agemm.matmul(qa, L["down"].W, sfa, L["down"].SFW, sa * L["down"].scale)
+        hn = F.rms_norm(hcur.view(bsz, q_len, -1)[:, -1], (cfg.hidden_size,), self.norm, cfg.eps)
+        return hn @ self.lm_head.t()
+
+
+def bench_decode(name="qwen2.5-7b", batch=4, prefill=1024, steps=16, device="cuda:0", repeats=3, layers=None):
+    """Decode tok/s with the decode step replayed from a HIP graph (attention window fixed at prefill+steps)."""
+    cfg = dataclasses.replace(MODEL_CFGS[name])
+    if layers:
+        cfg.num_layers = layers
+    device = torch.device(device)
+    with torch.no_grad():
+        model = DecoderModel(cfg, batch, prefill + steps + 1, device)
+        tok = torch.randint(100, 200, (batch, prefill), device=device)
+        t0 = time.perf_counter()
+        model.forward(tok, 0)
+        torch.cuda.synchronize()
+        t_prefill_first = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        model.forward(tok, 0)
+        torch.cuda.synchronize()
+        t_prefill = time.perf_counter() - t0
+        nxt = torch.randint(100, 200, (batch, 1), device=device)
+        pos = prefill + steps          # fixed attention window: the graph is shape-static
+        for _ in range(2):
+            model.forward(nxt, pos)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            model.forward(nxt, pos)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=s):
+                out = model.forward(nxt, pos)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(repeats):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / steps
+            best = ms if best is None else min(best, ms)
+        # eager (no graph) for comparison: host-paced
+        t0 = time.perf_counter()
+        for _ in range(4):
+            model.forward(nxt, pos)
+        torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - t0) / 4 * 1e3
+        wb = model.weight_bytes()
+        kv = 2 * cfg.num_layers * batch * cfg.hidden_size * pos * 2
+        assert out.shape == (batch, cfg.vocab_size)
+    return {"model": name, "layers": cfg.num_layers, "batch": batch, "prefill": prefill, "attn_window": pos,
+            "decode_ms_per_step_graph": round(best, 4), "decode_tok_per_s": round(batch / best * 1e3, 1),
+            "decode_ms_per_step_eager": round(eager_ms, 3), "prefill_ms": round(t_prefill * 1e3, 2),
+            "prefill_tok_per_s": round(batch * prefill / t_prefill, 0), "prefill_first_call_ms": round(t_prefill_first * 1e3, 1),
+            "weight_bytes": wb, "kv_bytes_read_per_step": kv,
+            "hbm_floor_ms_at_8TBps": round((wb + kv) / 8e12 * 1e3, 4)}
+
+
+if __name__ == "__main__":
+    import json
+    import sys
+    name = sys.argv[1] if len(sys.argv) > 1 else "qwen2.5-7b"
+    print(json.dumps(bench_decode(name)))

@@ -101,14 +101,20 @@ class ColumnParallelARCLinear:
         if not gather_output or self.world == 1:
             return y
         import torch.distributed as dist
-        widths = [b - a for a, b in self.ranges]
-        if len(set(widths)) == 1:
-            out = torch.empty((self.world,) + tuple(y.shape), dtype=y.dtype, device=y.device)
-            dist.all_gather_into_tensor(out, y.contiguous(), group=self.group)
-            return out.permute(1, 0, 2).reshape(y.shape[0], -1)
-        parts = [torch.empty((y.shape[0], w_), dtype=y.dtype, device=y.device) for w_ in widths]
-        dist.all_gather(parts, y.contiguous(), group=self.group)
-        return torch.cat(parts, dim=1)
+        return all_gather_columns(y, [b - a for a, b in self.ranges], group=self.group)
+
+
+def all_gather_columns(y: torch.Tensor, widths, group=None) -> torch.Tensor:
+    """All-gather column blocks of possibly different widths (collectives need equal shapes: pad to the widest)."""
+    import torch.distributed as dist
+    world, wmax = len(widths), max(widths)
+    if y.shape[1] < wmax:
+        y = torch.nn.functional.pad(y, (0, wmax - y.shape[1]))
+    rows = y.shape[0]
+    out = torch.empty((world * rows, wmax), dtype=y.dtype, device=y.device)     # ranks concatenated along dim 0
+    dist.all_gather_into_tensor(out, y.contiguous(), group=group)
+    out = out.view(world, rows, wmax)
+    return torch.cat([out[r, :, : widths[r]] for r in range(world)], dim=1)
 
 
 class RowParallelARCLinear:

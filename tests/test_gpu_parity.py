@@ -297,3 +297,51 @@ def test_baseline_size_gemm_against_fp64_matmul(M):
     assert torch.equal(got2, 2.0 * got)
     d16 = ag.matmul(A, B, SFA, SFB, alpha)
     assert torch.equal(d16, got.float().to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------------------------------------ host mirror
+def test_qlinear_layer_mirror_matches_oracle_pipeline():
+    """QLinearLayer + NVFP4_reorder_quantize_x (the reference's operator protocol, model/qLinearLayer.py:30-78,
+    model/qLlamaLayer.py:73-77) end to end against the oracle fed with the same torch pre-scaling."""
+    from arcquant_amd import qlinear
+    torch.manual_seed(0)
+    bsz, q_len, KQ, N, KE = 2, 3, 2048, 256, 64
+    lin = torch.nn.Linear(KQ, N, bias=True).to(torch.bfloat16).to(DEV)
+    idx = random_perm(KQ, 12)
+    layer = qlinear.QLinearLayer(lin, KE, idx)
+    x = outlier_activations(bsz * q_len, KQ, 13).to(DEV)
+    qx, scale_x, scale = qlinear.reorder_quantize_x(x, idx.to(DEV), KE)
+    y = layer((qx, scale_x, scale, bsz, q_len))
+    assert tuple(y.shape) == (bsz, q_len, N) and y.dtype == torch.bfloat16
+    # oracle on identical pre-scaled inputs
+    w = lin.weight.data
+    sw = torch.max(w).float() / 2688.0
+    sx = torch.max(x.abs()).float() / 2688.0
+    ow, owsf = O.quantize_w(bits((w / sw).contiguous()), idx.numpy(), KE, O.G16)
+    ox, oxsf = O.quantize_x(bits((x / sx).contiguous()), idx.numpy(), KE, O.G16)
+    assert np.array_equal(layer.W.cpu().numpy(), ow) and np.array_equal(qx.cpu().numpy(), ox)
+    want_bits, _ = O.gemm(ox, ow, oxsf, owsf, float(sx * sw))
+    want = (from_bits(want_bits) + lin.bias.data.cpu()).reshape(bsz, q_len, N)      # bias added after rounding, as the reference
+    assert _max_bf16_ulp_diff(bits(y), bits(want)) <= 2
+    assert (bits(y) == bits(want)).mean() > 0.98
+
+
+def test_gemm_with_subnormal_and_extreme_scales():
+    """Scale bytes in the e4m3 subnormal range (tiny activations) and at 448 (saturating rows) are decoded exactly
+    by the fp16-bit-pattern trick of gemm_common.hpp."""
+    ag = _agemm()
+    M, N, KQ = 4, 64, 256
+    x = torch.zeros(M, KQ, dtype=torch.bfloat16)
+    x[0] = 0.004                        # amax/6 below 2^-6 -> subnormal ue4m3 scale
+    x[1] = torch.linspace(-0.05, 0.05, KQ).to(torch.bfloat16)
+    x[2] = 2688.0                       # scale 448
+    x[3, ::3] = 1e-3
+    w = (torch.rand(N, KQ, generator=torch.Generator().manual_seed(2)) * 0.02 - 0.01).to(torch.bfloat16)
+    idx = np.arange(KQ, dtype=np.int16)
+    qx, sfx = O.quantize_x(bits(x), idx, 64, O.G16, sf_fill=0)
+    qw, sfw = O.quantize_w(bits(w), idx, 64, O.G16, sf_fill=0)
+    assert (sfx[:4 * 0 + 16] < 8).any() or (sfx < 8).any()      # subnormal scale bytes really occur
+    _, want, wabs = O.gemm(qx, qw, sfx, sfw, 1.0, want_abs=True)
+    got = ag.matmul(torch.from_numpy(qx).to(DEV), torch.from_numpy(qw).to(DEV), torch.from_numpy(sfx).to(DEV),
+                    torch.from_numpy(sfw).to(DEV), 1.0, out_dtype=torch.float32).cpu().numpy().astype(np.float64)
+    assert np.all(np.abs(got - want) <= 2e-6 * wabs + 1e-30)
