@@ -154,14 +154,15 @@ def matmul(A: torch.Tensor, B: torch.Tensor, SFA: torch.Tensor, SFB: torch.Tenso
 
 
 def absmax_scale(X: torch.Tensor) -> torch.Tensor:
-    """Extension: ``max|X| / (448*6)`` as a 1-element fp32 device tensor, no host sync.
-    Equals ``torch.max(x.abs()).float() / (448.0*6.0)`` of model/qLlamaLayer.py:74."""
+    """Extension: ``max|X| / (448*6)`` as a 0-dim fp32 device tensor, no host sync.
+    Equals ``torch.max(x.abs()).float() / (448.0*6.0)`` of model/qLlamaLayer.py:74 bit for bit (0-dim, so that
+    ``x / scale`` keeps x's dtype exactly as with the reference's scalar tensor)."""
     _need(X, torch.bfloat16, "X")
     out = torch.empty((1,), dtype=torch.float32, device=X.device)
     with torch.cuda.device(X.device):
         st = _lib.lib().arcq_absmax_scale(X.data_ptr(), X.numel(), out.data_ptr(), _stream(X))
     _lib.check(st, "absmax_scale")
-    return out
+    return out.reshape(())
 
 
 # --- KV-cache functions of the reference module (bindings.cpp:576-581): OUT OF SCOPE (SURVEY.md row 12).
