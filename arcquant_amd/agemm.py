@@ -103,13 +103,15 @@ def rmsnorm_quantize_x(X: torch.Tensor, W: torch.Tensor, eps: float, reorder_ind
     return QX, SFX
 
 
-def matmul(A: torch.Tensor, B: torch.Tensor, SFA: torch.Tensor, SFB: torch.Tensor, scale, *, bias=None,
-           out_dtype=torch.bfloat16, out=None):
+def matmul(A: torch.Tensor, B: torch.Tensor, SFA: torch.Tensor, SFB: torch.Tensor, scale, *, bias=None, residual=None,
+           out_dtype=torch.bfloat16, out=None, scale_host: float = 1.0):
     """agemm.matmul(A, B, SFA, SFB, scale) -> bf16 [M, N]  (bindings.cpp:99-120).
 
     ``scale`` may be a Python float (the reference's ``const float``) or a 0-dim / 1-element fp32 device
     tensor; the latter is consumed on the device (the reference converts it with an implicit ``.item()``
-    sync).  ``bias`` / ``out_dtype=torch.float32`` / ``out`` are extensions used by the host mirror.
+    sync).  Extensions used by the host mirror / e2e harness: ``bias`` (bf16 [N]), ``residual`` (bf16 [M,N], added
+    after the bf16 rounding, like ``x + linear(...)``), ``out_dtype=torch.float32``, ``out``, and ``scale_host`` (a host
+    float multiplied into a device ``scale``: weight scale x activation scale without a tiny multiply kernel).
     """
     _need(A, torch.uint8, "A", 2)
     _need(B, torch.uint8, "B", 2)
@@ -121,14 +123,14 @@ def matmul(A: torch.Tensor, B: torch.Tensor, SFA: torch.Tensor, SFB: torch.Tenso
     L = _lib.lib()
     if SFA.numel() < L.arcq_sf_used_bytes(M, K) or SFB.numel() < L.arcq_sf_used_bytes(N, K):
         raise RuntimeError("agemm.matmul: scale-factor buffer smaller than the swizzled layout of its operand")
-    alpha_host, alpha_dev = 1.0, None
+    alpha_host, alpha_dev = float(scale_host), None
     if isinstance(scale, torch.Tensor):
         if scale.is_cuda and scale.dtype == torch.float32 and scale.numel() == 1:
             alpha_dev = scale
         else:
-            alpha_host = float(scale)          # CPU tensor or other dtype: same as the reference's __float__
+            alpha_host *= float(scale)         # CPU tensor or other dtype: same as the reference's __float__
     else:
-        alpha_host = float(scale)
+        alpha_host *= float(scale)
     if out_dtype not in (torch.bfloat16, torch.float32):
         raise RuntimeError("agemm.matmul: out_dtype must be bfloat16 or float32")
     if out is None:
@@ -141,12 +143,17 @@ def matmul(A: torch.Tensor, B: torch.Tensor, SFA: torch.Tensor, SFB: torch.Tenso
         _need(bias, torch.bfloat16, "bias", 1)
         if bias.numel() != N:
             raise RuntimeError("agemm.matmul: bias must have N entries")
+    if residual is not None:
+        _need(residual, torch.bfloat16, "residual", 2)
+        if tuple(residual.shape) != (M, N):
+            raise RuntimeError("agemm.matmul: residual must be [M, N]")
     ws_bytes = int(L.arcq_gemm_workspace_bytes(M, N, K))
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=A.device) if ws_bytes else None
     with torch.cuda.device(A.device):
         st = L.arcq_gemm_nvfp4(A.data_ptr(), B.data_ptr(), SFA.data_ptr(), SFB.data_ptr(), out.data_ptr(), M, N, K,
                                alpha_host, alpha_dev.data_ptr() if alpha_dev is not None else None,
                                bias.data_ptr() if bias is not None else None,
+                               residual.data_ptr() if residual is not None else None,
                                OUT_BF16 if out_dtype == torch.bfloat16 else OUT_F32,
                                ws.data_ptr() if ws is not None else None, ws_bytes, _stream(A))
     _lib.check(st, "matmul")
@@ -163,6 +170,36 @@ def absmax_scale(X: torch.Tensor) -> torch.Tensor:
         st = _lib.lib().arcq_absmax_scale(X.data_ptr(), X.numel(), out.data_ptr(), _stream(X))
     _lib.check(st, "absmax_scale")
     return out.reshape(())
+
+
+_dyn_state = {}
+
+
+def reorder_quantize_x_dynamic(X: torch.Tensor, reorder_index: torch.Tensor, KE: int, variant=None):
+    """Extension: ``NVFP4_reorder_quantize_x`` (model/qLlamaLayer.py:73-77) in two launches, no host sync:
+    returns (QX, SFX, scale) with ``scale = max|X|/2688`` a 0-dim fp32 device tensor and (QX, SFX) byte-identical to
+    ``reorder_quantize_x(X / scale, reorder_index, KE)``."""
+    _need(X, torch.bfloat16, "X", 2)
+    _need(reorder_index, torch.int16, "reorder_index", 1)
+    M, KQ = X.shape
+    KE = int(KE)
+    K = KQ + KE
+    if variant is None:
+        variant = variant_for_kq(KQ)
+    if KQ % 16 or KE % 16 or KE < 0 or KE > KQ or K % 64 or reorder_index.numel() != KQ:
+        raise RuntimeError(f"Value error in reorder_quantize_x_dynamic: KQ={KQ}, KE={KE} is not valid")
+    dev = X.device
+    state = _dyn_state.get(dev)
+    if state is None:                      # 8 bytes, zero once; every call leaves it zero again
+        state = _dyn_state[dev] = torch.zeros(2, dtype=torch.int32, device=dev)
+    QX = torch.empty((M, K // 2), dtype=torch.uint8, device=dev)
+    SFX = torch.empty((sf_buffer_bytes(M, K),), dtype=torch.uint8, device=dev)
+    scale = torch.empty((1,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = _lib.lib().arcq_quantize_x_dyn(X.data_ptr(), reorder_index.data_ptr(), QX.data_ptr(), SFX.data_ptr(), scale.data_ptr(),
+                                            state.data_ptr(), M, KQ, KE, int(variant), _stream(X))
+    _lib.check(st, "reorder_quantize_x_dynamic")
+    return QX, SFX, scale.reshape(())
 
 
 # --- KV-cache functions of the reference module (bindings.cpp:576-581): OUT OF SCOPE (SURVEY.md row 12).

@@ -18,6 +18,8 @@ int quantize_w(const void* W, const int16_t* idx, uint8_t* QW, uint8_t* SFW, int
 int rmsnorm_quantize_x(const void* X, const void* Wn, float eps, const int16_t* idx, uint8_t* QX, uint8_t* SFX, int64_t M,
                        int64_t KQ, int64_t KE, int variant, hipStream_t stream);
 int absmax_scale(const void* X, int64_t n, float* scale_out, hipStream_t stream);
+int quantize_x_dyn(const void* X, const int16_t* idx, uint8_t* QX, uint8_t* SFX, float* scale_out, void* state, int64_t M,
+                   int64_t KQ, int64_t KE, int variant, hipStream_t stream);
 
 // gemm_skinny.hip / gemm_tile.hip
 struct GemmArgs {
@@ -30,6 +32,7 @@ struct GemmArgs {
   float alpha_host;
   const float* alpha_dev;   // optional device scalar multiplied into alpha
   const uint16_t* bias;     // optional bf16 [N]
+  const uint16_t* residual; // optional bf16 [M, N], added after the bf16 rounding of alpha*acc (+bias)
   int out_dtype;
   void* workspace;
   int64_t workspace_bytes;

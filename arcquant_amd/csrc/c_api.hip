@@ -67,6 +67,11 @@ int arcq_rmsnorm_quantize_x(const void* X, const void* W, float eps, const int16
   return rmsnorm_quantize_x(X, W, eps, reorder_index, QX, SFX, M, KQ, KE, variant, (hipStream_t)stream);
 }
 
+int arcq_quantize_x_dyn(const void* X, const int16_t* reorder_index, uint8_t* QX, uint8_t* SFX, float* scale_out, void* state,
+                        int64_t M, int64_t KQ, int64_t KE, int variant, void* stream) {
+  return quantize_x_dyn(X, reorder_index, QX, SFX, scale_out, state, M, KQ, KE, variant, (hipStream_t)stream);
+}
+
 int arcq_absmax_scale(const void* X, int64_t n, float* scale_out, void* stream) {
   return absmax_scale(X, n, scale_out, (hipStream_t)stream);
 }
@@ -85,7 +90,7 @@ int64_t arcq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
 }
 
 int arcq_gemm_nvfp4(const uint8_t* A, const uint8_t* B, const uint8_t* SFA, const uint8_t* SFB, void* D, int64_t M, int64_t N,
-                    int64_t K, float alpha_host, const float* alpha_dev, const void* bias, int out_dtype, void* workspace,
+                    int64_t K, float alpha_host, const float* alpha_dev, const void* bias, const void* residual, int out_dtype, void* workspace,
                     int64_t workspace_bytes, void* stream) {
   if (M < 0 || N < 0 || K <= 0 || (K % 64))
     return fail(ARCQ_ERR_SHAPE, "arcq_gemm_nvfp4: need M,N >= 0 and K %% 64 == 0 (M=%lld N=%lld K=%lld)", (long long)M,
@@ -102,7 +107,7 @@ int arcq_gemm_nvfp4(const uint8_t* A, const uint8_t* B, const uint8_t* SFA, cons
   GemmArgs a;
   a.A = A; a.B = B; a.SFA = SFA; a.SFB = SFB; a.D = D;
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
-  a.alpha_host = alpha_host; a.alpha_dev = alpha_dev; a.bias = (const uint16_t*)bias; a.out_dtype = out_dtype;
+  a.alpha_host = alpha_host; a.alpha_dev = alpha_dev; a.bias = (const uint16_t*)bias; a.residual = (const uint16_t*)residual; a.out_dtype = out_dtype;
   a.workspace = workspace; a.workspace_bytes = workspace_bytes;
   if (M <= kSkinnyMaxM) return gemm_skinny(a, (hipStream_t)stream);
   return gemm_tile(a, (hipStream_t)stream);

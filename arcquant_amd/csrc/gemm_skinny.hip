@@ -39,6 +39,7 @@ struct SkinnyParams {
   float* partial;         // [splitk, M, N] fp32 when splitk > 1
   const float* alpha_dev;
   const uint16_t* bias;
+  const uint16_t* residual;
   int M, N, K;
   float alpha_host;
   int out_dtype;
@@ -73,6 +74,10 @@ __device__ __forceinline__ void finish4(const SkinnyParams& p, int m, int n, con
   for (int r = 0; r < 4; ++r) {
     d[r] = alpha * acc[r];                                          // epilogue in fp32 (nvfp4.cu:117-121)
     if (p.bias && n + r < p.N) d[r] += bf16_bits_to_f32(p.bias[n + r]);
+    if (p.residual && n + r < p.N) {
+      const float res = bf16_bits_to_f32(p.residual[(size_t)m * p.N + n + r]);
+      d[r] = (p.out_dtype == ARCQ_OUT_F32 ? d[r] : bf16_bits_to_f32(f32_to_bf16_bits(d[r]))) + res;
+    }
   }
   store_out4(p, m, n, d);
 }
@@ -349,7 +354,7 @@ int gemm_skinny(const GemmArgs& a, hipStream_t stream) {
   SkinnyParams p;
   p.A = a.A; p.B = a.B; p.SFA = a.SFA; p.SFB = a.SFB; p.D = a.D;
   p.partial = reinterpret_cast<float*>(a.workspace);
-  p.alpha_dev = a.alpha_dev; p.bias = a.bias;
+  p.alpha_dev = a.alpha_dev; p.bias = a.bias; p.residual = a.residual;
   p.M = a.M; p.N = a.N; p.K = a.K; p.alpha_host = a.alpha_host; p.out_dtype = a.out_dtype;
   p.tiles = ((a.N + 127) / 128) * 8;
   p.slabs_per_split = per;

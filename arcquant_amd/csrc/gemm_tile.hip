@@ -33,6 +33,7 @@ struct TileParams {
   void* D;
   const float* alpha_dev;
   const uint16_t* bias;
+  const uint16_t* residual;
   int M, N, K;
   float alpha_host;
   int out_dtype;
@@ -243,6 +244,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
 #pragma unroll
       for (int r = 0; r < 4; ++r) if (n + r < p.N) d[r] += bf16_bits_to_f32(p.bias[n + r]);
     }
+    if (p.residual) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < p.N) {
+          const float res = bf16_bits_to_f32(p.residual[(size_t)m * p.N + n + r]);
+          d[r] = (p.out_dtype == ARCQ_OUT_F32 ? d[r] : bf16_bits_to_f32(f32_to_bf16_bits(d[r]))) + res;
+        }
+    }
     if (p.out_dtype == ARCQ_OUT_F32) {
       float* o = reinterpret_cast<float*>(p.D) + (size_t)m * p.N + n;
       if (vec_ok) *reinterpret_cast<float4*>(o) = make_float4(d[0], d[1], d[2], d[3]);
@@ -277,7 +286,7 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, bool kMfma32 = false>
 static int launch_tile(const GemmArgs& a, hipStream_t stream) {
   TileParams p;
   p.A = a.A; p.B = a.B; p.SFA = a.SFA; p.SFB = a.SFB; p.D = a.D;
-  p.alpha_dev = a.alpha_dev; p.bias = a.bias;
+  p.alpha_dev = a.alpha_dev; p.bias = a.bias; p.residual = a.residual;
   p.M = a.M; p.N = a.N; p.K = a.K; p.alpha_host = a.alpha_host; p.out_dtype = a.out_dtype;
   p.tiles_m = (a.M + BM - 1) / BM;
   p.tiles_n = (a.N + BN - 1) / BN;

@@ -85,10 +85,13 @@ __device__ __forceinline__ float rms_sumsq_tree(float* s, int bdx) {
   return s[0];
 }
 
+// `dyn` (kModeX only, may be NULL): {amax bits, ticket} of the per-tensor dynamic scale (arcq_quantize_x_dyn).  When
+// set, every element is first divided by scale = amax * (1/2688) and rounded to bf16 -- exactly what torch's GPU
+// `x / scale` with a 0-dim fp32 scale computes (model/qLlamaLayer.py:74-76) -- so the separate abs/max/div passes vanish.
 template <int kVariant, int kMode>
 __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
     const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wn, float eps, const int16_t* __restrict__ idx,
-    uint8_t* __restrict__ Q, uint8_t* __restrict__ SF, int rows, int KQ, int KE) {
+    uint8_t* __restrict__ Q, uint8_t* __restrict__ SF, int rows, int KQ, int KE, unsigned int* dyn, float* scale_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t* row_lds = reinterpret_cast<uint16_t*>(smem);
   float* red = reinterpret_cast<float*>(smem + (size_t)KQ * 2);   // kModeRms only
@@ -99,6 +102,14 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
   const int P = (KQ - KE) >> 4;
   const int chunks = KQ >> 3;           // 16-byte chunks per row
   const int bdx = KQ >> 4;              // the reference's block size (rmsnorm.cu:269-270)
+  float dyn_scale = 1.0f;
+  if (kMode == kModeX && dyn) {
+    dyn_scale = bf16_bits_to_f32(*reinterpret_cast<volatile unsigned int*>(dyn)) * (1.0f / (448.0f * 6.0f));
+    if (blockIdx.x == 0 && tid == 0) scale_out[0] = dyn_scale;      // the caller's fp32 per-tensor scale
+    // torch on the GPU divides a bf16 tensor by a 0-dim fp32 tensor in the COMMON dtype bf16: the scale operand is
+    // rounded to bf16 at load (BinaryFunctor<BFloat16, BFloat16, BFloat16, DivFunctor>), the quotient is formed in fp32
+    dyn_scale = bf16_bits_to_f32(f32_to_bf16_bits(dyn_scale));
+  }
 
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     const uint16_t* xrow = X + (size_t)row * KQ;
@@ -141,6 +152,10 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
       for (int j = 0; j < 8; ++j) {
         const uint32_t ia = iw[j] & 0xffffu, ib = iw[j] >> 16;
         float a = bf16_bits_to_f32(row_lds[ia]), b = bf16_bits_to_f32(row_lds[ib]);
+        if (kMode == kModeX && dyn) {                           // torch: bf16(float(x) / scale)
+          a = bf16_bits_to_f32(f32_to_bf16_bits(a / dyn_scale));
+          b = bf16_bits_to_f32(f32_to_bf16_bits(b / dyn_scale));
+        }
         if (kMode == kModeRms) {                                // rmsnorm.cu:165-171
           a = bf16_bits_to_f32(f32_to_bf16_bits(a * bf16_bits_to_f32(Wn[ia]) * rstd));
           b = bf16_bits_to_f32(f32_to_bf16_bits(b * bf16_bits_to_f32(Wn[ib]) * rstd));
@@ -182,6 +197,14 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
     }
     __syncthreads();   // row_lds is rewritten by the next row
   }
+  if (kMode == kModeX && dyn && tid == 0) {
+    // leave the state zeroed for the next call: the last workgroup to finish has seen every other one read it
+    __threadfence();
+    if (atomicAdd(dyn + 1, 1u) == gridDim.x - 1) {
+      dyn[0] = 0u;
+      dyn[1] = 0u;
+    }
+  }
 }
 
 // scale_out[0] = max|x| / 2688 (model/qLlamaLayer.py:73-77 without the host round trip).
@@ -219,7 +242,8 @@ constexpr int kMaxQuantBlocks = 2048;   // 256 CUs x 8 resident workgroups, rows
 
 template <int kMode>
 static int launch_quantize(const void* X, const void* Wn, float eps, const int16_t* idx, uint8_t* Q, uint8_t* SF,
-                           int64_t rows, int64_t KQ, int64_t KE, int variant, hipStream_t stream, const char* who) {
+                           int64_t rows, int64_t KQ, int64_t KE, int variant, hipStream_t stream, const char* who,
+                           unsigned int* dyn = nullptr, float* scale_out = nullptr) {
   if (rows < 0 || KQ <= 0 || (KQ % 16) || (KE % 16) || KE < 0 || KE > KQ || ((KQ + KE) % 64))
     return fail(ARCQ_ERR_SHAPE, "%s: need KQ%%16==0, KE%%16==0, 0<=KE<=KQ, (KQ+KE)%%64==0 (rows=%lld KQ=%lld KE=%lld)", who,
                 (long long)rows, (long long)KQ, (long long)KE);
@@ -244,7 +268,7 @@ static int launch_quantize(const void* X, const void* Wn, float eps, const int16
       if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "%s: cannot reserve %zu B of LDS: %s", who, lds, hipGetErrorString(e));
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kQuantThreads), lds, stream, (const uint16_t*)X, (const uint16_t*)Wn, eps, idx,
-                       Q, SF, (int)rows, (int)KQ, (int)KE);
+                       Q, SF, (int)rows, (int)KQ, (int)KE, dyn, scale_out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "%s: launch failed: %s", who, hipGetErrorString(e));
     return ARCQ_OK;
@@ -264,6 +288,24 @@ int quantize_w(const void* W, const int16_t* idx, uint8_t* QW, uint8_t* SFW, int
 int rmsnorm_quantize_x(const void* X, const void* Wn, float eps, const int16_t* idx, uint8_t* QX, uint8_t* SFX, int64_t M,
                        int64_t KQ, int64_t KE, int variant, hipStream_t stream) {
   return launch_quantize<kModeRms>(X, Wn, eps, idx, QX, SFX, M, KQ, KE, variant, stream, "arcq_rmsnorm_quantize_x");
+}
+
+int quantize_x_dyn(const void* X, const int16_t* idx, uint8_t* QX, uint8_t* SFX, float* scale_out, void* state, int64_t M,
+                   int64_t KQ, int64_t KE, int variant, hipStream_t stream) {
+  if (!scale_out || !state) return fail(ARCQ_ERR_NULL, "arcq_quantize_x_dyn: NULL scale_out / state");
+  // validate the shape first (rows = 0 runs every check and launches nothing): a failure after the abs-max
+  // launch would leave a stale maximum in `state`
+  const int rc = launch_quantize<kModeX>(X, nullptr, 0.f, idx, QX, SFX, 0, KQ, KE, variant, stream, "arcq_quantize_x_dyn");
+  if (rc != ARCQ_OK || M <= 0) return rc;
+  if (!X || !idx || !QX || !SFX) return fail(ARCQ_ERR_NULL, "arcq_quantize_x_dyn: NULL pointer");
+  if ((reinterpret_cast<uintptr_t>(X) & 15) != 0) return fail(ARCQ_ERR_SHAPE, "arcq_quantize_x_dyn: X must be 16-byte aligned");
+  if (KQ <= 0 || (KQ % 16)) return fail(ARCQ_ERR_SHAPE, "arcq_quantize_x_dyn: KQ %% 16 != 0");
+  unsigned int* st = reinterpret_cast<unsigned int*>(state);
+  const int64_t n = M * KQ, n8 = n / 8;
+  int64_t want = (n8 + 255) / 256;
+  const int grid = (int)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
+  hipLaunchKernelGGL(absmax_bits_kernel, dim3(grid), dim3(256), 0, stream, (const uint16_t*)X, n8, n, st);
+  return launch_quantize<kModeX>(X, nullptr, 0.f, idx, QX, SFX, M, KQ, KE, variant, stream, "arcq_quantize_x_dyn", st, scale_out);
 }
 
 int absmax_scale(const void* X, int64_t n, float* scale_out, hipStream_t stream) {

@@ -48,7 +48,9 @@ MODEL_CFGS = {
 
 
 class QLinear:
-    """Quantised weight of one linear (random init), model/qLinearLayer.py:30-62 without the nn.Module shell."""
+    """Quantised weight of one linear (random init), model/qLinearLayer.py:30-62 without the nn.Module shell.
+    ``out_f`` may be the concatenation of several projections that share their input (q|k|v, gate|up): they are
+    then quantised as ONE tensor (one per-tensor scale) and computed by one GEMM launch."""
 
     def __init__(self, in_f, out_f, select_num, device, gen):
         w = (torch.randn(out_f, in_f, generator=gen, device=device, dtype=torch.float32) * 0.02).to(torch.bfloat16)
@@ -56,6 +58,7 @@ class QLinear:
         scale = torch.max(w).float() / (448.0 * 6.0)
         self.W, self.SFW = agemm.reorder_quantize_w((w / scale).contiguous(), self.idx, select_num)
         self.scale = scale.reshape(1)
+        self.scale_f = float(scale)          # one sync at load time; lets alpha = scale_f * (device activation scale)
         self.in_f, self.out_f, self.KE = in_f, out_f, select_num
 
     def bytes(self):
@@ -63,17 +66,25 @@ class QLinear:
 
 
 class DecoderModel:
-    def __init__(self, cfg: ModelConfig, batch: int, max_len: int, device):
-        self.cfg, self.device, self.batch, self.max_len = cfg, device, batch, max_len
+    """fused=False: the reference's call structure (model/qLlamaLayer.py: separate q/k/v and gate/up GEMMs, torch
+    abs/max/div before each activation quantise, torch residual adds).  fused=True: q|k|v and gate|up as one GEMM each,
+    `reorder_quantize_x_dynamic` (2 launches instead of 5), residual add in the GEMM epilogue."""
+
+    def __init__(self, cfg: ModelConfig, batch: int, max_len: int, device, fused: bool = False, attention: str = "current"):
+        """attention="current": what benchmarks/modeling_arc.py:169-198 times -- K/V are appended to the cache and each
+        sequence attends (causally) over its CURRENT tokens only; attention="cache": attend over the whole KV cache."""
+        self.cfg, self.device, self.batch, self.max_len, self.fused = cfg, device, batch, max_len, fused
+        self.attention = attention
         g = torch.Generator(device=device).manual_seed(0)
         h, it, ke = cfg.hidden_size, cfg.intermediate_size, cfg.select_num
         self.layers = []
         for _ in range(cfg.num_layers):
             self.layers.append(dict(
                 ln1=torch.ones(h, dtype=torch.bfloat16, device=device), ln2=torch.ones(h, dtype=torch.bfloat16, device=device),
-                q=QLinear(h, h, ke, device, g), k=QLinear(h, h, ke, device, g), v=QLinear(h, h, ke, device, g),
-                o=QLinear(h, h, ke, device, g), gate=QLinear(h, it, ke, device, g), up=QLinear(h, it, ke, device, g),
-                down=QLinear(it, h, ke, device, g),
+                **(dict(qkv=QLinear(h, 3 * h, ke, device, g), gateup=QLinear(h, 2 * it, ke, device, g)) if fused else
+                   dict(q=QLinear(h, h, ke, device, g), k=QLinear(h, h, ke, device, g), v=QLinear(h, h, ke, device, g),
+                        gate=QLinear(h, it, ke, device, g), up=QLinear(h, it, ke, device, g))),
+                o=QLinear(h, h, ke, device, g), down=QLinear(it, h, ke, device, g),
                 kc=torch.zeros(batch, cfg.num_heads, max_len, h // cfg.num_heads, dtype=torch.bfloat16, device=device),
                 vc=torch.zeros(batch, cfg.num_heads, max_len, h // cfg.num_heads, dtype=torch.bfloat16, device=device)))
         self.idx_h = torch.arange(h, dtype=torch.int16, device=device)
@@ -84,7 +95,7 @@ class DecoderModel:
         self.one = torch.ones(1, dtype=torch.float32, device=device)
 
     def weight_bytes(self):
-        per_layer = sum(self.layers[0][k].bytes() for k in ("q", "k", "v", "o", "gate", "up", "down"))
+        per_layer = sum(v.bytes() for v in self.layers[0].values() if isinstance(v, QLinear))
         return per_layer * self.cfg.num_layers + self.lm_head.numel() * 2
 
     @staticmethod
@@ -100,36 +111,57 @@ class DecoderModel:
         bsz, q_len = tokens.shape
         nh, hd = cfg.num_heads, cfg.hidden_size // cfg.num_heads
         hcur = self.embed[tokens].reshape(bsz * q_len, cfg.hidden_size)
+        h, it = cfg.hidden_size, cfg.intermediate_size
         for L in self.layers:
             A, SFA = agemm.rmsnorm_quantize_x(hcur, L["ln1"], cfg.eps, self.idx_h, cfg.select_num)
-            q = agemm.matmul(A, L["q"].W, SFA, L["q"].SFW, L["q"].scale)
-            k = agemm.matmul(A, L["k"].W, SFA, L["k"].SFW, L["k"].scale)
-            v = agemm.matmul(A, L["v"].W, SFA, L["v"].SFW, L["v"].scale)
-            q = q.view(bsz, q_len, nh, hd).transpose(1, 2)
-            L["kc"][:, :, pos:pos + q_len] = k.view(bsz, q_len, nh, hd).transpose(1, 2)
-            L["vc"][:, :, pos:pos + q_len] = v.view(bsz, q_len, nh, hd).transpose(1, 2)
-            att = F.scaled_dot_product_attention(q, L["kc"][:, :, :pos + q_len], L["vc"][:, :, :pos + q_len], is_causal=(q_len > 1 and pos == 0))
+            if self.fused:
+                qkv = agemm.matmul(A, L["qkv"].W, SFA, L["qkv"].SFW, L["qkv"].scale)
+                q, k, v = qkv[:, :h], qkv[:, h:2 * h], qkv[:, 2 * h:]
+            else:
+                q = agemm.matmul(A, L["q"].W, SFA, L["q"].SFW, L["q"].scale)
+                k = agemm.matmul(A, L["k"].W, SFA, L["k"].SFW, L["k"].scale)
+                v = agemm.matmul(A, L["v"].W, SFA, L["v"].SFW, L["v"].scale)
+            q = q.reshape(bsz, q_len, nh, hd).transpose(1, 2)
+            L["kc"][:, :, pos:pos + q_len] = k.reshape(bsz, q_len, nh, hd).transpose(1, 2)
+            L["vc"][:, :, pos:pos + q_len] = v.reshape(bsz, q_len, nh, hd).transpose(1, 2)
+            if self.attention == "cache":
+                att = F.scaled_dot_product_attention(q, L["kc"][:, :, :pos + q_len], L["vc"][:, :, :pos + q_len],
+                                                     is_causal=(q_len > 1 and pos == 0))
+            else:
+                att = F.scaled_dot_product_attention(q, k.reshape(bsz, q_len, nh, hd).transpose(1, 2),
+                                                     v.reshape(bsz, q_len, nh, hd).transpose(1, 2), is_causal=q_len > 1)
             att = att.transpose(1, 2).reshape(bsz * q_len, cfg.hidden_size)
-            qa, sfa, sa = self._quant_x(att, self.idx_h, cfg.select_num)
-            hcur = hcur + agemm.matmul(qa, L["o"].W, sfa, L["o"].SFW, sa * L["o"].scale)
+            if self.fused:
+                qa, sfa, sa = agemm.reorder_quantize_x_dynamic(att, self.idx_h, cfg.select_num)
+                hcur = agemm.matmul(qa, L["o"].W, sfa, L["o"].SFW, sa, scale_host=L["o"].scale_f, residual=hcur)
+            else:
+                qa, sfa, sa = self._quant_x(att, self.idx_h, cfg.select_num)
+                hcur = hcur + agemm.matmul(qa, L["o"].W, sfa, L["o"].SFW, sa * L["o"].scale)
             A, SFA = agemm.rmsnorm_quantize_x(hcur, L["ln2"], cfg.eps, self.idx_h, cfg.select_num)
-            gate = agemm.matmul(A, L["gate"].W, SFA, L["gate"].SFW, L["gate"].scale)
-            up = agemm.matmul(A, L["up"].W, SFA, L["up"].SFW, L["up"].scale)
-            act = F.silu(gate) * up
-            qa, sfa, sa = self._quant_x(act, self.idx_i, cfg.select_num)
-            hcur = hcur + agemm.matmul(qa, L["down"].W, sfa, L["down"].SFW, sa * L["down"].scale)
+            if self.fused:
+                gu = agemm.matmul(A, L["gateup"].W, SFA, L["gateup"].SFW, L["gateup"].scale)
+                act = F.silu(gu[:, :it]) * gu[:, it:]
+                qa, sfa, sa = agemm.reorder_quantize_x_dynamic(act, self.idx_i, cfg.select_num)
+                hcur = agemm.matmul(qa, L["down"].W, sfa, L["down"].SFW, sa, scale_host=L["down"].scale_f, residual=hcur)
+            else:
+                gate = agemm.matmul(A, L["gate"].W, SFA, L["gate"].SFW, L["gate"].scale)
+                up = agemm.matmul(A, L["up"].W, SFA, L["up"].SFW, L["up"].scale)
+                act = F.silu(gate) * up
+                qa, sfa, sa = self._quant_x(act, self.idx_i, cfg.select_num)
+                hcur = hcur + agemm.matmul(qa, L["down"].W, sfa, L["down"].SFW, sa * L["down"].scale)
         hn = F.rms_norm(hcur.view(bsz, q_len, -1)[:, -1], (cfg.hidden_size,), self.norm, cfg.eps)
         return hn @ self.lm_head.t()
 
 
-def bench_decode(name="qwen2.5-7b", batch=4, prefill=1024, steps=16, device="cuda:0", repeats=3, layers=None):
+def bench_decode(name="qwen2.5-7b", batch=4, prefill=1024, steps=16, device="cuda:0", repeats=3, layers=None, fused=False,
+                 attention="current"):
     """Decode tok/s with the decode step replayed from a HIP graph (attention window fixed at prefill+steps)."""
     cfg = dataclasses.replace(MODEL_CFGS[name])
     if layers:
         cfg.num_layers = layers
     device = torch.device(device)
     with torch.no_grad():
-        model = DecoderModel(cfg, batch, prefill + steps + 1, device)
+        model = DecoderModel(cfg, batch, prefill + steps + 1, device, fused=fused, attention=attention)
         tok = torch.randint(100, 200, (batch, prefill), device=device)
         t0 = time.perf_counter()
         model.forward(tok, 0)
@@ -171,9 +203,9 @@ def bench_decode(name="qwen2.5-7b", batch=4, prefill=1024, steps=16, device="cud
         torch.cuda.synchronize()
         eager_ms = (time.perf_counter() - t0) / 4 * 1e3
         wb = model.weight_bytes()
-        kv = 2 * cfg.num_layers * batch * cfg.hidden_size * pos * 2
+        kv = 2 * cfg.num_layers * batch * cfg.hidden_size * pos * 2 if attention == "cache" else 0
         assert out.shape == (batch, cfg.vocab_size)
-    return {"model": name, "layers": cfg.num_layers, "batch": batch, "prefill": prefill, "attn_window": pos,
+    return {"model": name, "fused": fused, "attention": attention, "layers": cfg.num_layers, "batch": batch, "prefill": prefill, "attn_window": pos,
             "decode_ms_per_step_graph": round(best, 4), "decode_tok_per_s": round(batch / best * 1e3, 1),
             "decode_ms_per_step_eager": round(eager_ms, 3), "prefill_ms": round(t_prefill * 1e3, 2),
             "prefill_tok_per_s": round(batch * prefill / t_prefill, 0), "prefill_first_call_ms": round(t_prefill_first * 1e3, 1),
@@ -185,4 +217,6 @@ if __name__ == "__main__":
     import json
     import sys
     name = sys.argv[1] if len(sys.argv) > 1 else "qwen2.5-7b"
-    print(json.dumps(bench_decode(name)))
+    for fused, att in ((False, "current"), (True, "current"), (True, "cache")):
+        print(json.dumps(bench_decode(name, fused=fused, attention=att)))
+        torch.cuda.empty_cache()

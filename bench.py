@@ -156,6 +156,11 @@ def bench_extra(args, device, rank):
     try:
         from arcquant_amd.e2e import bench_decode
         extra["qwen2.5-7b_decode"] = bench_decode("qwen2.5-7b", batch=4, prefill=1024, steps=16, device=device)
+        torch.cuda.empty_cache()
+        extra["qwen2.5-7b_decode_fused"] = bench_decode("qwen2.5-7b", batch=4, prefill=1024, steps=16, device=device, fused=True)
+        torch.cuda.empty_cache()
+        extra["qwen2.5-7b_decode_fused_full_cache_attention"] = bench_decode("qwen2.5-7b", batch=4, prefill=1024, steps=16, device=device,
+                                                                             fused=True, attention="cache")
     except Exception as e:  # the e2e harness is optional for the headline number
         extra["qwen2.5-7b_decode"] = {"error": f"{type(e).__name__}: {e}"}
     return extra

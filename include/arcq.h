@@ -99,10 +99,13 @@ int64_t arcq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
  *   A [M,K/2], B [N,K/2] packed e2m1; SFA/SFB swizzled ue4m3; K % 64 == 0.
  *   alpha = alpha_host * (alpha_dev ? *alpha_dev : 1): the reference takes a host float
  *   (bindings.cpp:104); alpha_dev lets callers keep the per-tensor scale on the device (no sync).
- *   bias (optional, bf16 [N]) is added after scaling, before rounding.  out_dtype: ARCQ_OUT_*.
+ *   bias (optional, bf16 [N]) is added after scaling, before rounding.  residual (optional, bf16 [M,N], may alias D)
+ *   is added AFTER the bf16 rounding and the sum is rounded again -- the two-step rounding of the caller's
+ *   `x + linear(...)` in bf16.  out_dtype: ARCQ_OUT_* (fp32 output adds both in fp32, one result).
  *   workspace / workspace_bytes: scratch of at least arcq_gemm_workspace_bytes(M,N,K) (may be NULL if 0). */
 int arcq_gemm_nvfp4(const uint8_t *A, const uint8_t *B, const uint8_t *SFA, const uint8_t *SFB, void *D, int64_t M,
-                    int64_t N, int64_t K, float alpha_host, const float *alpha_dev, const void *bias, int out_dtype,
+                    int64_t N, int64_t K, float alpha_host, const float *alpha_dev, const void *bias, const void *residual,
+                    int out_dtype,
                     void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ---- f1 extension: per-tensor scale on the device (replaces torch.max(x.abs())/2688 + x/scale,
@@ -110,6 +113,13 @@ int arcq_gemm_nvfp4(const uint8_t *A, const uint8_t *B, const uint8_t *SFA, cons
 
 /* scale_out[0] = max|x| / (448*6) as fp32; x is bf16 [n]. */
 int arcq_absmax_scale(const void *X, int64_t n, float *scale_out, void *stream);
+
+/* NVFP4_reorder_quantize_x (model/qLlamaLayer.py:73-77) in two launches instead of five:
+ *   scale = max|X| / 2688 (fp32, written to scale_out[0]);  (QX, SFX) = arcq_quantize_x(bf16(X / scale), ...).
+ * `state` is 8 bytes of device memory owned by the caller that must be ZERO before the first call; every call
+ * leaves it zero again (the last workgroup resets it), so no memset is needed between calls or graph replays. */
+int arcq_quantize_x_dyn(const void *X, const int16_t *reorder_index, uint8_t *QX, uint8_t *SFX, float *scale_out,
+                        void *state, int64_t M, int64_t KQ, int64_t KE, int variant, void *stream);
 
 /* ---- debug (tuning only): the decode GEMM writes 8 x u64 wall-clock (100 MHz) stamps per workgroup into
  *      dev_buf while it is non-NULL: [0] start, [1] prefetch issued, [2] first item landed, [3] last item

@@ -62,8 +62,8 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert L.arcq_quantize_x(None, None, None, None, 4, 4096, 64, 7, None) == -1       # bad variant
     assert L.arcq_quantize_x(None, None, None, None, 4, 4096, 64, 0, None) == -4       # NULL pointers
     assert L.arcq_quantize_x(None, None, None, None, 0, 4096, 64, 0, None) == 0        # empty input is fine
-    assert L.arcq_gemm_nvfp4(None, None, None, None, None, 4, 4, 100, 1.0, None, None, 0, None, 0, None) == -1
-    assert L.arcq_gemm_nvfp4(None, None, None, None, None, 0, 4, 128, 1.0, None, None, 0, None, 0, None) == 0
+    assert L.arcq_gemm_nvfp4(None, None, None, None, None, 4, 4, 100, 1.0, None, None, None, 0, None, 0, None) == -1
+    assert L.arcq_gemm_nvfp4(None, None, None, None, None, 0, 4, 128, 1.0, None, None, None, 0, None, 0, None) == 0
     assert L.arcq_rmsnorm_quantize_x(None, None, 1e-6, None, None, None, 4, 1024, 0, 0, None) == -2   # outside [2048, 8192]
     with pytest.raises(_lib.ArcqError):
         _lib.check(-1, "demo")

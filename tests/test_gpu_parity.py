@@ -345,3 +345,42 @@ def test_gemm_with_subnormal_and_extreme_scales():
     got = ag.matmul(torch.from_numpy(qx).to(DEV), torch.from_numpy(qw).to(DEV), torch.from_numpy(sfx).to(DEV),
                     torch.from_numpy(sfw).to(DEV), 1.0, out_dtype=torch.float32).cpu().numpy().astype(np.float64)
     assert np.all(np.abs(got - want) <= 2e-6 * wabs + 1e-30)
+
+
+def test_dynamic_quantizer_equals_torch_prescale_pipeline():
+    """reorder_quantize_x_dynamic == the reference's three-step wrapper (model/qLlamaLayer.py:73-77:
+    scale = max|x|/2688; x/scale in torch; reorder_quantize_x) byte for byte, for decode- and prefill-sized inputs,
+    and repeated calls keep working (the 8-byte state resets itself)."""
+    ag = _agemm()
+    for (M, KQ, KE) in [(4, 3584, 64), (1, 4096, 64), (300, 2048, 128), (4, 18944, 64)]:
+        x = outlier_activations(M, KQ, 40 + M).to(DEV)
+        idx = random_perm(KQ, 41).to(DEV)
+        for _ in range(2):
+            scale = torch.max(x.abs()).float() / (448.0 * 6.0)
+            want_q, want_sf = ag.reorder_quantize_x((x / scale).contiguous(), idx, KE)
+            got_q, got_sf, got_scale = ag.reorder_quantize_x_dynamic(x, idx, KE)
+            assert got_scale.item() == scale.item()
+            assert torch.equal(got_q, want_q)
+            K = KQ + KE
+            used = torch.zeros(got_sf.numel(), dtype=torch.bool)
+            r = torch.arange(M).unsqueeze(1)
+            p = torch.arange(K // 16).unsqueeze(0)
+            off = ((r // 128) * (K // 64) + p // 4) * 512 + (r % 32) * 16 + ((r // 32) % 4) * 4 + p % 4
+            used[off.reshape(-1)] = True
+            assert torch.equal(got_sf.cpu()[used], want_sf.cpu()[used])
+            x = -x * 0.5       # second round with a different maximum
+
+
+def test_gemm_residual_epilogue_matches_torch_add():
+    ag = _agemm()
+    for M in (4, 130):
+        qx, sfx, qw, sfw, alpha = _make_operands(M, 256, 512, 64, O.G16, 77 + M)
+        A, B = torch.from_numpy(qx).to(DEV), torch.from_numpy(qw).to(DEV)
+        SFA, SFB = torch.from_numpy(sfx).to(DEV), torch.from_numpy(sfw).to(DEV)
+        res = torch.randn(M, 256, generator=torch.Generator().manual_seed(M)).to(torch.bfloat16).to(DEV)
+        want = res + ag.matmul(A, B, SFA, SFB, alpha)                     # torch: bf16 + bf16, rounded once more
+        got = ag.matmul(A, B, SFA, SFB, alpha, residual=res)
+        assert torch.equal(got, want)
+        dev_scale = torch.tensor(alpha / 0.25, dtype=torch.float32, device=DEV)
+        got2 = ag.matmul(A, B, SFA, SFB, dev_scale, scale_host=0.25, residual=res)
+        assert torch.equal(got2, want)
