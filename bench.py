@@ -255,6 +255,14 @@ def main():
         elapsed = float(t.item())
 
     flops = gemm_flops(M, N, K)
+    # HBM traffic per launch from the committed PMC passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE);
+    # bench.py cannot run rocprofv3 on itself, so the number is read from profiles/ and labelled as such
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_tile_gemm.json")) as f:
+            traffic = json.load(f)["per_launch"]["hbm_traffic_bytes"]
+    except Exception:
+        pass
     value = world * flops * args.steps / elapsed / 1e12
     achieved = flops / kern_us / 1e6   # TFLOP/s of one launch of the dominant kernel, HIP-event timed
 
@@ -268,7 +276,8 @@ def main():
                                "exact e2m1 x ue4m3 products on fp16 MFMA with fp32 accumulate, bf16 out",
                    "M": M, "N_per_rank": N, "KQ": KQ, "KE": KE, "parallelism": f"column-parallel x{world} (no collective)"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": None,
+                     "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic,
+                     "traffic_source": "profiles/r01_pmc_tile_gemm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)",
                      "kernel": "arcq::gemm_tile_kernel", "kernel_us": round(kern_us, 2),
                      "frac_of_fp4_peak": round(achieved / PEAK_FP4_TFLOPS, 4),
                      "note": "NVFP4 (ue4m3 scale per 16) has no exact mapping onto gfx950's E8M0-per-32 scaled fp4 MFMA; the exact "
