@@ -46,19 +46,39 @@ __device__ __forceinline__ GroupQ quantize_group(float (&v)[16]) {
   s = fminf(fmaxf(s, kScaleEps), kFp8Max);
   GroupQ g;
   g.s_raw = s;
-  g.s8 = f32_to_ue4m3(s);
+  // gfx950 conversion instructions, probed (tools/probe_gfx950.hip) and byte-checked against the oracle by the GPU
+  // tests: v_cvt_pk_fp8_f32 is OCP e4m3 RNE incl. subnormals (s is already clamped to [2^-9, 448]);
+  // v_cvt_scalef32_pk_fp4_f32 is RNE, ties to the even code, saturating at +-6 (== clamp then convert,
+  // reorder.cu:153), sign of zero kept; v_cvt_scalef32_pk_f32_fp4 decodes two codes.  Scale operands are 1.0.
+  g.s8 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(s, s, 0, false) & 0xffu;
   g.s_round = ue4m3_to_f32(g.s8);
   const float r = 1.0f / g.s_round;              // == (float)(1.0/(double)s8), tests/test_oracle_formats.py
   const float S = (kVariant == ARCQ_VARIANT_G16) ? g.s_round : g.s_raw;   // reorder.cu:157 vs :474
   uint32_t lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(lo, v[0] * r, v[1] * r, 1.0f, 0);
+  lo = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(lo, v[2] * r, v[3] * r, 1.0f, 1);
+  lo = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(lo, v[4] * r, v[5] * r, 1.0f, 2);
+  lo = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(lo, v[6] * r, v[7] * r, 1.0f, 3);
+  hi = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(hi, v[8] * r, v[9] * r, 1.0f, 0);
+  hi = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(hi, v[10] * r, v[11] * r, 1.0f, 1);
+  hi = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(hi, v[12] * r, v[13] * r, 1.0f, 2);
+  hi = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(hi, v[14] * r, v[15] * r, 1.0f, 3);
+  if (kResid) {
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    float q = fminf(fmaxf(v[i] * r, -kFp4Max), kFp4Max);
-    uint32_t c = f32_to_e2m1(q);
-    if (i < 8) lo |= c << (4 * i); else hi |= c << (4 * (i - 8));
-    if (kResid) {
-      float d = __builtin_fmaf(-e2m1_to_f32(c), S, v[i]);   // fused, oracle assumption A2
-      v[i] = bf16_bits_to_f32(f32_to_bf16_bits(d));
+    for (int b = 0; b < 8; ++b) {
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const uint32_t w = b < 4 ? lo : hi;
+      f32x2 q2;
+      switch (b & 3) {
+        case 0: q2 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 1.0f, 0); break;
+        case 1: q2 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 1.0f, 1); break;
+        case 2: q2 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 1.0f, 2); break;
+        default: q2 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 1.0f, 3); break;
+      }
+      const float d0 = __builtin_fmaf(-q2.x, S, v[2 * b]);       // fused, oracle assumption A2
+      const float d1 = __builtin_fmaf(-q2.y, S, v[2 * b + 1]);
+      v[2 * b] = bf16_bits_to_f32(f32_to_bf16_bits(d0));
+      v[2 * b + 1] = bf16_bits_to_f32(f32_to_bf16_bits(d1));
     }
   }
   g.packed = make_uint2(lo, hi);
