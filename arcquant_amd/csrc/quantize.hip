@@ -205,7 +205,13 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
       } else if (!tail) {
         GroupQ q = quantize_group<false, kVariant>(v);
         *reinterpret_cast<uint2*>(qrow + (size_t)p * 8) = q.packed;
-        SF[sf_offset(row, p, K)] = (uint8_t)q.s8;
+        // outside the outlier tail p == g, so the four lanes of a quad own the four bytes of ONE aligned dword of
+        // the swizzled scale layout (P and G are multiples of 4): gather them and store once
+        uint32_t w = q.s8;
+        w |= (uint32_t)__shfl_down((int)q.s8, 1, 4) << 8;
+        w |= (uint32_t)__shfl_down((int)q.s8, 2, 4) << 16;
+        w |= (uint32_t)__shfl_down((int)q.s8, 3, 4) << 24;
+        if ((tid & 3) == 0) *reinterpret_cast<uint32_t*>(SF + sf_offset(row, p, K)) = w;
       } else {                                                   // residual: reorder.cu:166-198, 499-550
         GroupQ q = quantize_group<true, kVariant>(v);
         *reinterpret_cast<uint2*>(qrow + (size_t)p * 8) = q.packed;
