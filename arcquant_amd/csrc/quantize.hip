@@ -122,10 +122,15 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
   const int P = (KQ - KE) >> 4;
   const int chunks = KQ >> 3;           // 16-byte chunks per row
   const int bdx = KQ >> 4;              // the reference's block size (rmsnorm.cu:269-270)
+  // decode-sized inputs (a handful of rows) are split along the row as well: blockIdx.y owns a 4-aligned range of
+  // groups; every workgroup still stages the whole row (the gather may touch any channel), which is an L2 hit
+  const int g_per = (((G + (int)gridDim.y - 1) / (int)gridDim.y) + 3) & ~3;
+  const int g_begin = (int)blockIdx.y * g_per;
+  const int g_end = min(G, g_begin + g_per);
   float dyn_scale = 1.0f;
   if (kMode == kModeX && dyn) {
     dyn_scale = bf16_bits_to_f32(*reinterpret_cast<volatile unsigned int*>(dyn)) * (1.0f / (448.0f * 6.0f));
-    if (blockIdx.x == 0 && tid == 0) scale_out[0] = dyn_scale;      // the caller's fp32 per-tensor scale
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) scale_out[0] = dyn_scale;      // the caller's fp32 per-tensor scale
     // torch on the GPU divides a bf16 tensor by a 0-dim fp32 tensor in the COMMON dtype bf16: the scale operand is
     // rounded to bf16 at load (BinaryFunctor<BFloat16, BFloat16, BFloat16, DivFunctor>), the quotient is formed in fp32
     dyn_scale = bf16_bits_to_f32(f32_to_bf16_bits(dyn_scale));
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
     }
 
     uint8_t* qrow = Q + (size_t)row * (K >> 1);
-    for (int g = tid; g < G; g += kQuantThreads) {
+    for (int g = g_begin + tid; g < g_end; g += kQuantThreads) {
       // reorder_index for this group: 16 x int16 = two 16-byte loads
       const uint4 i0 = *reinterpret_cast<const uint4*>(idx + (size_t)g * 16);
       const uint4 i1 = *reinterpret_cast<const uint4*>(idx + (size_t)g * 16 + 8);
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
   if (kMode == kModeX && dyn && tid == 0) {
     // leave the state zeroed for the next call: the last workgroup to finish has seen every other one read it
     __threadfence();
-    if (atomicAdd(dyn + 1, 1u) == gridDim.x - 1) {
+    if (atomicAdd(dyn + 1, 1u) == gridDim.x * gridDim.y - 1) {
       dyn[0] = 0u;
       dyn[1] = 0u;
     }
@@ -288,12 +293,15 @@ static int launch_quantize(const void* X, const void* Wn, float eps, const int16
 
   size_t lds = (size_t)KQ * 2 + (kMode == kModeRms ? 512 * sizeof(float) : 0);
   const int grid = (int)(rows < kMaxQuantBlocks ? rows : kMaxQuantBlocks);
+  // few rows (decode): also split each row over up to 16 workgroups of >= 32 groups so that the chip is not idle
+  int gsplit = 1;
+  while (grid * gsplit < 256 && gsplit < 16 && (KQ / 16) / (gsplit * 2) >= 32) gsplit *= 2;
   auto go = [&](auto kern) -> int {
     if (lds > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "%s: cannot reserve %zu B of LDS: %s", who, lds, hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kQuantThreads), lds, stream, (const uint16_t*)X, (const uint16_t*)Wn, eps, idx,
+    hipLaunchKernelGGL(kern, dim3(grid, gsplit), dim3(kQuantThreads), lds, stream, (const uint16_t*)X, (const uint16_t*)Wn, eps, idx,
                        Q, SF, (int)rows, (int)KQ, (int)KE, dyn, scale_out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "%s: launch failed: %s", who, hipGetErrorString(e));
