@@ -212,13 +212,21 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py: for --gpus N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ...`")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # Rehearsal switches (not used by the driver): ARCQ_BENCH_ONE_DEVICE=1 maps every rank to cuda:0 and
+    # ARCQ_BENCH_BACKEND=gloo replaces RCCL, so the N > 1 code path can be exercised on a one-GPU box.
+    one_device = os.environ.get("ARCQ_BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("ARCQ_BENCH_BACKEND", "nccl")
+    dev_index = 0 if one_device else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from arcquant_amd import agemm
 

@@ -384,3 +384,31 @@ def test_gemm_residual_epilogue_matches_torch_add():
         dev_scale = torch.tensor(alpha / 0.25, dtype=torch.float32, device=DEV)
         got2 = ag.matmul(A, B, SFA, SFB, dev_scale, scale_host=0.25, residual=res)
         assert torch.equal(got2, want)
+
+
+def test_decode_and_tile_kernels_agree_and_full_residual_width():
+    """The same 16 tokens through the decode kernel (M=16) and as the first rows of an M=48 call (tile kernel) give the
+    same fp32 result up to accumulation order; KE == KQ (every channel carries a residual) is handled by both."""
+    ag = _agemm()
+    KQ = KE = 512
+    qx, sfx, qw, sfw, alpha = _make_operands(48, 192, KQ, KE, O.G16, 321)
+    A, B = torch.from_numpy(qx).to(DEV), torch.from_numpy(qw).to(DEV)
+    SFA, SFB = torch.from_numpy(sfx).to(DEV), torch.from_numpy(sfw).to(DEV)
+    big = ag.matmul(A, B, SFA, SFB, alpha, out_dtype=torch.float32)
+    # rows 0..15 share the first 128-row scale tile, so the same scale buffer is valid for the 16-row call
+    small = ag.matmul(A[:16].contiguous(), B, SFA, SFB, alpha, out_dtype=torch.float32)
+    _, want, wabs = O.gemm(qx, qw, sfx, sfw, alpha, want_abs=True)
+    assert np.all(np.abs(big.cpu().numpy() - want) <= 2e-6 * wabs + 1e-30)
+    assert np.all(np.abs(small.cpu().numpy() - want[:16]) <= 2e-6 * wabs[:16] + 1e-30)
+    assert torch.allclose(big[:16], small, rtol=1e-5, atol=1e-5 * float(big.abs().max()))
+
+
+@pytest.mark.parametrize("M,N", [(1, 1), (2, 16), (16, 17), (33, 1)])
+def test_gemm_tiny_output_shapes(M, N):
+    ag = _agemm()
+    qx, sfx, qw, sfw, alpha = _make_operands(M, N, 256, 64, O.G16, 900 + M + N)
+    _, want, wabs = O.gemm(qx, qw, sfx, sfw, alpha, want_abs=True)
+    got = ag.matmul(torch.from_numpy(qx).to(DEV), torch.from_numpy(qw).to(DEV), torch.from_numpy(sfx).to(DEV),
+                    torch.from_numpy(sfw).to(DEV), alpha, out_dtype=torch.float32).cpu().numpy()
+    assert got.shape == (M, N)
+    assert np.all(np.abs(got - want) <= 2e-6 * wabs + 1e-30)
