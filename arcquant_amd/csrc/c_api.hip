@@ -86,7 +86,7 @@ static const int64_t kSkinnyMaxM = 16;
 
 int64_t arcq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  return M <= kSkinnyMaxM ? gemm_skinny_workspace_bytes(M, N, K) : 0;
+  return M <= kSkinnyMaxM ? gemm_skinny_workspace_bytes(M, N, K) : gemm_tile_workspace_bytes(M, N, K);
 }
 
 int arcq_gemm_nvfp4(const uint8_t* A, const uint8_t* B, const uint8_t* SFA, const uint8_t* SFB, void* D, int64_t M, int64_t N,

@@ -297,6 +297,18 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(SkinnyParams p, int 
   finish4(p, m, n, s);
 }
 
+int gemm_splitk_finish(const GemmArgs& a, int splitk, hipStream_t stream) {
+  SkinnyParams p{};
+  p.D = a.D; p.partial = reinterpret_cast<float*>(a.workspace);
+  p.alpha_dev = a.alpha_dev; p.bias = a.bias; p.residual = a.residual;
+  p.M = a.M; p.N = a.N; p.K = a.K; p.alpha_host = a.alpha_host; p.out_dtype = a.out_dtype;
+  const int64_t quads = ((int64_t)a.M * a.N + 3) / 4;
+  hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p, splitk);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_gemm_nvfp4 (split-K finish): launch failed: %s", hipGetErrorString(e));
+  return ARCQ_OK;
+}
+
 // split-K (over whole items) only when the tiles alone leave most CUs idle
 static void choose_split(int64_t N, int64_t K, int slab_k, int* splitk, int* slabs_per_split) {
   const int64_t tiles = ((N + 127) / 128) * 8;
@@ -369,12 +381,9 @@ int gemm_skinny(const GemmArgs& a, hipStream_t stream) {
     return fail(ARCQ_ERR_UNSUPPORTED, "arcq_gemm_nvfp4 (skinny): operand larger than 4 GiB");
   const int rc = waves == 16 ? launch_skinny<16>(p, splitk, stream) : launch_skinny<8>(p, splitk, stream);
   if (rc != ARCQ_OK) return rc;
-  if (splitk > 1) {
-    const int64_t quads = ((int64_t)a.M * a.N + 3) / 4;
-    hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p, splitk);
-  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_gemm_nvfp4 (skinny): launch failed: %s", hipGetErrorString(e));
+  if (splitk > 1) return gemm_splitk_finish(a, splitk, stream);
   return ARCQ_OK;
 }
 

@@ -33,8 +33,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
   constexpr int kT = kMfma32 ? 32 : 16;                   // MFMA tile edge
   constexpr int TM = WM / kT, TN = WN / kT;               // MFMA tiles per wave
   using acc_t = typename std::conditional<kMfma32, f32x16, f32x4>::type;
-  static_assert((BM * 2) % kThreads == 0 && (BN * 2) % kThreads == 0, "whole staging units per thread");
-  constexpr int A_UNITS = BM * 2 / kThreads, B_UNITS = BN * 2 / kThreads;   // 16-byte staging units per thread
+  static_assert((BN * 2) % kThreads == 0, "whole staging units per thread");
+  // 16-byte staging units per thread; a short A tile (BM*2 < kThreads) leaves the upper threads without a unit
+  constexpr int A_UNITS = (BM * 2 + kThreads - 1) / kThreads, B_UNITS = BN * 2 / kThreads;
+  constexpr bool A_PARTIAL = (BM * 2) % kThreads != 0;
+  static_assert(!A_PARTIAL || A_UNITS == 1, "a partial A pass is a single pass");
   constexpr int A_TILE = BM * kRowBytes, B_TILE = BN * kRowBytes;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -46,7 +49,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
   // ---- XCD-aware tile order: blocks that land on one XCD (id % 8) get a contiguous range of tiles, and
   //      within it tiles walk M fastest in groups of 8 so concurrently resident blocks share B panels.
   const int ntiles = p.tiles_m * p.tiles_n;
-  int bid = blockIdx.x;
+  int bid = blockIdx.x, split = 0;
+  if (p.splits > 1) {
+    split = bid / ntiles;
+    bid -= split * ntiles;
+  }
   {
     const int q8 = ntiles >> 3, r8 = ntiles & 7, x = bid & 7, j = bid >> 3;
     bid = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + j;     // bijective for any ntiles
@@ -64,6 +71,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WAVES_N, wc = wave % WAVES_N;
   const int half_k = p.K >> 1, atoms_k = p.K >> 6;
+  const int a_begin = split * p.atoms_per_split, a_end = min(atoms_k, a_begin + p.atoms_per_split);   // never empty
 
   // ---- per-thread staging geometry (loop invariant)
   const uint8_t* a_q[A_UNITS];
@@ -72,7 +80,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
   int a_slot[A_UNITS][4];
 #pragma unroll
   for (int u = 0; u < A_UNITS; ++u) {
-    const int unit = tid + u * kThreads, r = unit >> 1, h = unit & 1;
+    const int unit = tid + u * kThreads, r = A_PARTIAL ? min(unit >> 1, BM - 1) : unit >> 1, h = unit & 1;
     const int row = m0 + r, rc = row < p.M ? row : p.M - 1;
     a_q[u] = p.A + (size_t)rc * half_k + h * 16;
     a_sf[u] = p.SFA + sf_atom_offset(rc, 0, atoms_k) + h * 2;
@@ -115,7 +123,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
   };
   auto store_step = [&](unsigned char* la, unsigned char* lb) {
 #pragma unroll
-    for (int u = 0; u < A_UNITS; ++u) stage_store(la, a_slot[u], sa[u], a_live[u]);
+    for (int u = 0; u < A_UNITS; ++u)
+      if (!A_PARTIAL || tid < BM * 2) stage_store(la, a_slot[u], sa[u], a_live[u]);
 #pragma unroll
     for (int u = 0; u < B_UNITS; ++u) stage_store(lb, b_slot[u], sb[u], b_live[u]);
   };
@@ -158,27 +167,28 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
     for (int u = 0; u < A_UNITS; ++u) ta[u] = sa[u];
 #pragma unroll
     for (int u = 0; u < B_UNITS; ++u) tb[u] = sb[u];
-    load_step(min(kt + 2, atoms_k - 1));          // in flight during this whole step
+    load_step(min(kt + 2, a_end - 1));            // in flight during this whole step
     __builtin_amdgcn_sched_barrier(0);            // keep the loads at the top: hipcc otherwise sinks them to the barrier
     mma_step(ca, cb);
 #pragma unroll
-    for (int u = 0; u < A_UNITS; ++u) stage_store(na, a_slot[u], ta[u], a_live[u]);
+    for (int u = 0; u < A_UNITS; ++u)
+      if (!A_PARTIAL || tid < BM * 2) stage_store(na, a_slot[u], ta[u], a_live[u]);
 #pragma unroll
     for (int u = 0; u < B_UNITS; ++u) stage_store(nb, b_slot[u], tb[u], b_live[u]);
     __syncthreads();
   };
 
   // ---- prologue: tile 0 into buffer 0, registers <- step 1
-  load_step(0);
+  load_step(a_begin);
   store_step(lds_a0, lds_b0);
-  load_step(min(1, atoms_k - 1));
+  load_step(min(a_begin + 1, a_end - 1));
   __syncthreads();
-  int kt = 0;
-  for (; kt + 1 < atoms_k; kt += 2) {
+  int kt = a_begin;
+  for (; kt + 1 < a_end; kt += 2) {
     k_step(kt, lds_a0, lds_b0, lds_a1, lds_b1);
     k_step(kt + 1, lds_a1, lds_b1, lds_a0, lds_b0);
   }
-  if (kt < atoms_k) k_step(kt, lds_a0, lds_b0, lds_a1, lds_b1);
+  if (kt < a_end) k_step(kt, lds_a0, lds_b0, lds_a1, lds_b1);
 
   // ---- epilogue.  16x16 tiles: lane holds D[m = +(lane & 15)][n = +4*(lane >> 4) + r], r = 0..3.
   //      32x32 tiles: lane holds D[m = +(lane & 31)][n = +8*g + 4*(lane >> 5) + r], g = 0..3, r = 0..3.
@@ -186,6 +196,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
   const bool vec_ok = (p.N & 3) == 0;
   auto store4 = [&](int m, int n, float d0, float d1, float d2, float d3) {
     if (m >= p.M || n >= p.N) return;
+    if (p.splits > 1) {                       // raw partial sums; the launcher only splits when N % 4 == 0
+      *reinterpret_cast<float4*>(p.partial + ((size_t)split * p.M + m) * p.N + n) = make_float4(d0, d1, d2, d3);
+      return;
+    }
     float d[4] = {alpha * d0, alpha * d1, alpha * d2, alpha * d3};
     if (p.bias) {
 #pragma unroll
@@ -229,28 +243,53 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
   }
 }
 
+// Split-K factor of a tile shape: split while the tiles alone leave CUs idle, keeping >= 8 atoms (512 K elements)
+// per split so that the prologue/epilogue stay amortised; needs N % 4 == 0 (16-byte partial stores).
+static void tile_split(int64_t M, int64_t N, int64_t K, int BM, int BN, int* splits, int* atoms_per_split) {
+  const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  const int atoms = (int)(K / 64);
+  int s = 1;
+  if ((N % 4) == 0)
+    while (tiles * s < 256 && atoms / (s * 2) >= 8 && s < 32) s *= 2;
+  const int per = (atoms + s - 1) / s;
+  *splits = (atoms + per - 1) / per;      // drop empty splits
+  *atoms_per_split = per;
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool kMfma32 = false>
-static int launch_tile(const GemmArgs& a, hipStream_t stream) {
+static int launch_tile(const GemmArgs& a, hipStream_t stream, bool allow_split = false) {
   TileParams p;
   p.A = a.A; p.B = a.B; p.SFA = a.SFA; p.SFB = a.SFB; p.D = a.D;
   p.alpha_dev = a.alpha_dev; p.bias = a.bias; p.residual = a.residual;
   p.M = a.M; p.N = a.N; p.K = a.K; p.alpha_host = a.alpha_host; p.out_dtype = a.out_dtype;
   p.tiles_m = (a.M + BM - 1) / BM;
   p.tiles_n = (a.N + BN - 1) / BN;
+  p.splits = 1; p.atoms_per_split = a.K / 64; p.partial = nullptr;
+  if (allow_split) {
+    tile_split(a.M, a.N, a.K, BM, BN, &p.splits, &p.atoms_per_split);
+    if (p.splits > 1) {
+      const int64_t need = (int64_t)p.splits * a.M * a.N * (int64_t)sizeof(float);
+      if (!a.workspace || a.workspace_bytes < need)
+        return fail(ARCQ_ERR_WORKSPACE, "arcq_gemm_nvfp4: split-K needs %lld B of workspace, got %lld", (long long)need,
+                    (long long)a.workspace_bytes);
+      p.partial = reinterpret_cast<float*>(a.workspace);
+    }
+  }
   const size_t lds = 2 * (size_t)(BM + BN) * kRowBytes;
   auto kern = gemm_tile_kernel<BM, BN, WAVES_M, WAVES_N, kMfma32>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_gemm_nvfp4 (tile): cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(WAVES_M * WAVES_N * 64), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n * p.splits)), dim3(WAVES_M * WAVES_N * 64), lds, stream, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_gemm_nvfp4 (tile): launch failed: %s", hipGetErrorString(e));
+  if (p.splits > 1) return gemm_splitk_finish(a, p.splits, stream);
   return ARCQ_OK;
 }
 
 // ARCQ_TILE_CFG (debug / tuning only): 0 = heuristic, 1 = 128x128 (4 waves), 2 = 256x256 (4 waves),
-// 3 = 256x256 (8 waves), 4 = 128x256 (4 waves)
+// 3 = 256x256 (8 waves), 4 = 128x256 (4 waves), 5/6 = 32x32x16 MFMA variants, 7 = 64x256, 8 = 32x256 (split-K)
 static int tile_cfg_override() {
   static const int v = [] {
     const char* e = getenv("ARCQ_TILE_CFG");
@@ -259,22 +298,56 @@ static int tile_cfg_override() {
   return v;
 }
 
+// Shape -> tile: 256x256 with 8 waves (one workgroup per CU, two waves per SIMD) once it yields enough tiles to
+// fill the 256 CUs (measured, tools/gemm_sweep.py: 4096^2 1066 vs 762 TFLOP/s, 8192^2 1347 vs 984); otherwise
+// 128x128 (two workgroups per CU), or a 64- / 32-row tile over 256 weight rows for M <= 64 / 32, each with split-K.
+enum TileKind { kTile256, kTile128, kTile64, kTile32 };
+static TileKind tile_kind(int64_t M, int64_t N) {
+  const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
+  if (t256 >= 192) return kTile256;
+  if (M <= 32) return kTile32;
+  if (M <= 64) return kTile64;
+  return kTile128;
+}
+
+int64_t gemm_tile_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  int s = 1, per = 0;
+  int kind = (int)tile_kind(M, N);
+  switch (tile_cfg_override()) {            // tuning override: the split of the forced tile
+    case 0: break;
+    case 1: kind = kTile128; break;
+    case 7: kind = kTile64; break;
+    case 8: kind = kTile32; break;
+    default: kind = kTile256; break;
+  }
+  switch (kind) {
+    case kTile128: tile_split(M, N, K, 128, 128, &s, &per); break;
+    case kTile64: tile_split(M, N, K, 64, 256, &s, &per); break;
+    case kTile32: tile_split(M, N, K, 32, 256, &s, &per); break;
+    default: break;
+  }
+  return s > 1 ? (int64_t)s * M * N * (int64_t)sizeof(float) : 0;
+}
+
 int gemm_tile(const GemmArgs& a, hipStream_t stream) {
   switch (tile_cfg_override()) {
-    case 1: return launch_tile<128, 128, 2, 2>(a, stream);
+    case 1: return launch_tile<128, 128, 2, 2>(a, stream, true);
     case 2: return launch_tile<256, 256, 2, 2>(a, stream);
     case 3: return launch_tile<256, 256, 2, 4>(a, stream);
     case 4: return launch_tile<128, 256, 2, 2>(a, stream);
     case 5: return launch_tile<256, 256, 2, 4, true>(a, stream);
     case 6: return launch_tile<128, 128, 2, 2, true>(a, stream);
+    case 7: return launch_tile<64, 256, 1, 4>(a, stream, true);
+    case 8: return launch_tile<32, 256, 1, 4>(a, stream, true);
+    case 9: return launch_tile<128, 128, 2, 2>(a, stream, false);
     default: break;
   }
-  // 256x256 with 8 waves (one workgroup per CU, two waves per SIMD) once it yields enough tiles to fill the
-  // 256 CUs; 128x128 (two workgroups per CU) otherwise.  Measured on MI355X (tools/gemm_sweep.py):
-  // 4096^2: 1066 vs 762 TFLOP/s, 8192^2: 1347 vs 984.
-  const int64_t t256 = ((int64_t)(a.M + 255) / 256) * ((a.N + 255) / 256);
-  if (t256 >= 192) return launch_tile<256, 256, 2, 4>(a, stream);
-  return launch_tile<128, 128, 2, 2>(a, stream);
+  switch (tile_kind(a.M, a.N)) {
+    case kTile256: return launch_tile<256, 256, 2, 4>(a, stream);
+    case kTile64: return launch_tile<64, 256, 1, 4>(a, stream, true);
+    case kTile32: return launch_tile<32, 256, 1, 4>(a, stream, true);
+    default: return launch_tile<128, 128, 2, 2>(a, stream, true);
+  }
 }
 
 }  // namespace arcq

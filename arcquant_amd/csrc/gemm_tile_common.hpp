@@ -22,6 +22,10 @@ struct TileParams {
   float alpha_host;
   int out_dtype;
   int tiles_m, tiles_n;
+  // split-K (shapes whose tiles alone leave CUs idle): workgroup blockIdx.x / (tiles_m*tiles_n) owns the scale-factor
+  // atoms [split*atoms_per_split, +atoms_per_split) and writes raw fp32 sums to partial[split][M][N]
+  int splits, atoms_per_split;
+  float* partial;
 };
 
 constexpr int kBK = 64;                 // K elements per step = one scale-factor atom column (4 groups)

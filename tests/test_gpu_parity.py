@@ -159,6 +159,11 @@ GEMM_CASES = [
     (130, 200, 256, 0, O.G16),        # ragged M and N on the tile kernel
     (128, 384, 1024, 128, O.G32),
     (300, 130, 320, 0, O.G16),        # N % 4 != 0 (scalar store path)
+    (24, 260, 1984, 64, O.G16),       # 32-row tile, split-K x4, ragged 256-row weight tiles
+    (33, 516, 2048, 64, O.G16),       # 64-row tile (33 live rows), split-K
+    (100, 384, 2048, 128, O.G32),     # 128x128 tile, split-K
+    (40, 130, 2048, 0, O.G16),        # N % 4 != 0: the split is refused, one pass over K
+    (520, 256, 1024, 64, O.G16),      # several M tiles x split-K
 ]
 
 
@@ -373,8 +378,8 @@ def test_dynamic_quantizer_equals_torch_prescale_pipeline():
 
 def test_gemm_residual_epilogue_matches_torch_add():
     ag = _agemm()
-    for M in (4, 130):
-        qx, sfx, qw, sfw, alpha = _make_operands(M, 256, 512, 64, O.G16, 77 + M)
+    for M, KQ in ((4, 512), (130, 512), (40, 1984), (90, 1984)):          # the last two finish through split-K
+        qx, sfx, qw, sfw, alpha = _make_operands(M, 256, KQ, 64, O.G16, 77 + M)
         A, B = torch.from_numpy(qx).to(DEV), torch.from_numpy(qw).to(DEV)
         SFA, SFB = torch.from_numpy(sfx).to(DEV), torch.from_numpy(sfw).to(DEV)
         res = torch.randn(M, 256, generator=torch.Generator().manual_seed(M)).to(torch.bfloat16).to(DEV)
