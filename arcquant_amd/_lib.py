@@ -35,7 +35,6 @@ SYMBOLS = {
     "arcq_gemm_nvfp4": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _f32, _p, _p, _p, _i32, _p, _i64, _p]),
     "arcq_absmax_scale": (_i32, [_p, _i64, _p, _p]),
     "arcq_quantize_x_dyn": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p]),
-    "arcq_debug_set_trace": (_i32, [_p]),
 }
 
 _lib = None

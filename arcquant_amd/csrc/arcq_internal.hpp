@@ -43,6 +43,5 @@ int64_t gemm_tile_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int gemm_splitk_finish(const GemmArgs& a, int splitk, hipStream_t stream);
 int gemm_skinny(const GemmArgs& a, hipStream_t stream);   // M <= 16: weight-streaming MFMA GEMV
 int gemm_tile(const GemmArgs& a, hipStream_t stream);     // general M: LDS-tiled MFMA GEMM
-extern void* g_trace_buf;                                 // debug stamps of the skinny kernel (8 x u64 per workgroup)
 
 }  // namespace arcq

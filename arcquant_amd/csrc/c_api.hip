@@ -76,11 +76,6 @@ int arcq_absmax_scale(const void* X, int64_t n, float* scale_out, void* stream) 
   return absmax_scale(X, n, scale_out, (hipStream_t)stream);
 }
 
-// Debug only: device buffer (>= 8 * 8 bytes per workgroup) that receives wall-clock stamps of the decode GEMM.
-int arcq_debug_set_trace(void* dev_buf) {
-  g_trace_buf = dev_buf;
-  return ARCQ_OK;
-}
 
 static const int64_t kSkinnyMaxM = 16;
 

@@ -45,20 +45,22 @@ struct SkinnyParams {
   int out_dtype;
   int tiles;              // ceil(N / 16)
   int slabs_per_split;
-  unsigned long long* trace;   // debug: per-workgroup wall-clock stamps (arcq_debug_set_trace), normally NULL
 };
 
+// Idx = uint32_t inside the decode kernel (M <= 16: element offsets fit 32 bits, so the address is an SGPR base
+// plus one VGPR offset instead of a 64-bit VGPR pair per lane -- the kernel is register bound), size_t elsewhere.
+template <typename Idx>
 __device__ __forceinline__ void store_out4(const SkinnyParams& p, int m, int n, const float (&d)[4]) {
   // d[r] is the finished value of D[m, n + r]
   if (p.out_dtype == ARCQ_OUT_F32) {
-    float* o = reinterpret_cast<float*>(p.D) + (size_t)m * p.N + n;
+    float* o = reinterpret_cast<float*>(p.D) + ((Idx)m * (Idx)p.N + (Idx)n);
     if (n + 3 < p.N && (p.N & 3) == 0) {
       *reinterpret_cast<float4*>(o) = make_float4(d[0], d[1], d[2], d[3]);
     } else {
       for (int r = 0; r < 4; ++r) if (n + r < p.N) o[r] = d[r];
     }
   } else {
-    uint16_t* o = reinterpret_cast<uint16_t*>(p.D) + (size_t)m * p.N + n;
+    uint16_t* o = reinterpret_cast<uint16_t*>(p.D) + ((Idx)m * (Idx)p.N + (Idx)n);
     if (n + 3 < p.N && (p.N & 3) == 0) {
       *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3]));
     } else {
@@ -67,19 +69,19 @@ __device__ __forceinline__ void store_out4(const SkinnyParams& p, int m, int n, 
   }
 }
 
-__device__ __forceinline__ void finish4(const SkinnyParams& p, int m, int n, const float (&acc)[4]) {
-  const float alpha = p.alpha_host * (p.alpha_dev ? *p.alpha_dev : 1.0f);
+template <typename Idx>
+__device__ __forceinline__ void finish4(const SkinnyParams& p, float alpha, int m, int n, const float (&acc)[4]) {
   float d[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     d[r] = alpha * acc[r];                                          // epilogue in fp32 (nvfp4.cu:117-121)
     if (p.bias && n + r < p.N) d[r] += bf16_bits_to_f32(p.bias[n + r]);
     if (p.residual && n + r < p.N) {
-      const float res = bf16_bits_to_f32(p.residual[(size_t)m * p.N + n + r]);
+      const float res = bf16_bits_to_f32(p.residual[(Idx)m * (Idx)p.N + (Idx)(n + r)]);
       d[r] = (p.out_dtype == ARCQ_OUT_F32 ? d[r] : bf16_bits_to_f32(f32_to_bf16_bits(d[r]))) + res;
     }
   }
-  store_out4(p, m, n, d);
+  store_out4<Idx>(p, m, n, d);
 }
 
 // A workgroup of kWaves wave64 walks items of kWaves*128 K elements: one 16-byte unit per thread (loader role), one
@@ -103,7 +105,7 @@ struct SkinnyCfg {
 struct ItemRegs {
   uint4 b;             // loader role: this thread's 16-byte unit of packed B
   uint4 a;             // loader role (token rows only): 16-byte unit of packed A
-  uint32_t sa;         // ... and the two scale bytes of that unit
+  uint32_t sa;         // ... and the four scale bytes of its atom (the unit uses two of them)
   uint32_t sb;         // compute role: this lane's 4 scale bytes (one atom) of B for its wave's chunk
 };
 
@@ -136,8 +138,9 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gemm_skinny_kernel(SkinnyParam
   const bool m_ok = rl < p.M;
   const bool a_loader = ld_rho < p.M;
 
-  unsigned long long* tr = p.trace ? p.trace + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
-  if (tr && tid == 0) tr[0] = wall_clock64();
+  // read before the ring starts: a load consumed inside the item loop would have to wait for every ring load
+  // issued before it (vmcnt is an in-order counter)
+  const float alpha = p.alpha_host * (p.alpha_dev ? *p.alpha_dev : 1.0f);
 
   // A tile's 16 rows are {128*T + 32*j + 4*t + i}: rho = 4j + i
   const int ld_rowpart = (ld_rho >> 2) * 32 + (ld_rho & 3);
@@ -146,8 +149,8 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gemm_skinny_kernel(SkinnyParam
   const uint32_t k_last = half_k - 16u;                                        // clamp for the partial tail slab
   const uint32_t sfb_lane = (rl & 3) * 16 + (rl >> 2) * 4 + (2 * wave + (q >> 1)) * 512 + (uint32_t)slab_begin * kSlabAtoms * 512u;
   const uint32_t sfb_small = (rl & 3) * 16 + (rl >> 2) * 4;
-  const uint32_t sfa_first = (uint32_t)ld_rho * 16 + ((uint32_t)slab_begin * kSlabAtoms + (ld_u >> 1)) * 512u + (ld_u & 1) * 2;
-  const uint32_t sfa_last = (uint32_t)ld_rho * 16 + (uint32_t)(atoms_k - 1) * 512u + (ld_u & 1) * 2;
+  const uint32_t sfa_first = (uint32_t)ld_rho * 16 + ((uint32_t)slab_begin * kSlabAtoms + (ld_u >> 1)) * 512u;   // the atom's aligned dword
+  const uint32_t sfa_last = (uint32_t)ld_rho * 16 + (uint32_t)(atoms_k - 1) * 512u;
 
   // ---- issue side state (runs kRing items ahead of the compute side); all offsets are carried incrementally
   int iss_tile = blockIdx.x, iss_slab = 0, issued = 0;
@@ -160,17 +163,18 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gemm_skinny_kernel(SkinnyParam
   };
   issue_tile_setup();
   uint32_t k_cur = k_first, sfb_cur = sfb_lane, sfa_cur = sfa_first;
-  const uint32_t a_row = (uint32_t)ld_rho * half_k;
+  const uint32_t a_row = (uint32_t)min(ld_rho, p.M - 1) * half_k;        // token rows >= M duplicate the last one (never stored)
+  // Every thread issues the SAME loads for every item (rows clamped, nothing predicated): only then can the
+  // compiler count them and wait with vmcnt(N) for the oldest item while the younger ones stay in flight -- with
+  // predicated loads it falls back to vmcnt(0) and the ring collapses to one item.  The cursor stops at the last
+  // item, so the ring's final refills re-read valid memory.
   auto issue_next = [&](ItemRegs& r) {
-    if (issued < nitems) {                                     // wave-uniform
-      const uint32_t koff = min(k_cur, k_last);
-      r.b = *reinterpret_cast<const uint4*>(p.B + (size_t)(b_row + koff));
-      r.sb = *reinterpret_cast<const uint32_t*>(p.SFB + (size_t)min(sfb_row + sfb_cur, sfb_rowmax));
-      if (a_loader) {
-        r.a = *reinterpret_cast<const uint4*>(p.A + (size_t)(a_row + koff));
-        r.sa = *reinterpret_cast<const uint16_t*>(p.SFA + (size_t)min(sfa_cur, sfa_last));
-      }
-      ++issued;
+    const uint32_t koff = min(k_cur, k_last);
+    r.b = *reinterpret_cast<const uint4*>(p.B + (size_t)(b_row + koff));
+    r.sb = *reinterpret_cast<const uint32_t*>(p.SFB + (size_t)min(sfb_row + sfb_cur, sfb_rowmax));
+    r.a = *reinterpret_cast<const uint4*>(p.A + (size_t)(a_row + koff));
+    r.sa = *reinterpret_cast<const uint32_t*>(p.SFA + (size_t)min(sfa_cur, sfa_last));   // dword: a 16-bit load is widened at once, i.e. waited for
+    if (issued + 1 < nitems) {                                 // wave-uniform, address arithmetic only
       k_cur += kSlabBytes; sfb_cur += kSlabAtoms * 512u; sfa_cur += kSlabAtoms * 512u;
       if (++iss_slab == nslabs) {
         iss_slab = 0; iss_tile += G;
@@ -178,18 +182,15 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gemm_skinny_kernel(SkinnyParam
         issue_tile_setup();
       }
     }
+    ++issued;
   };
 
-  // Code size matters as much as instruction count here: every launch starts with a cold instruction cache and
-  // most of this kernel runs exactly once per workgroup, so the item loop is ROLLED (the register ring advances
-  // by moves instead of by unrolling) and the per-tile epilogue exists once.
+  // The register ring is addressed BY NAME (the item loop is unrolled three times): rotating it with moves would
+  // read the registers of the youngest load and so wait for it, collapsing the ring to a single item in flight.
   ItemRegs r0, r1, r2;
-  r0.b = r0.a = r1.b = r1.a = r2.b = r2.a = make_uint4(0, 0, 0, 0);
-  r0.sb = r0.sa = r1.sb = r1.sa = r2.sb = r2.sa = 0;
   issue_next(r0);
   issue_next(r1);
   issue_next(r2);
-  if (tr && tid == 0) tr[1] = wall_clock64();
 
   // the spare token row of both A images stays zero; MFMA columns >= M read it
   if (ld_rho == 0) {
@@ -210,78 +211,83 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gemm_skinny_kernel(SkinnyParam
   const int lane_atom = slab_begin * kSlabAtoms + 2 * wave + (q >> 1);   // compute role: atom of slab 0
   const int ld_atom = slab_begin * kSlabAtoms + (ld_u >> 1);             // loader role (A): atom of slab 0
   int parity = 0;
-  bool first = true;
+  int cur_tile = blockIdx.x, cur_slab = 0;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll 1
-  for (int cur_tile = blockIdx.x; cur_tile < p.tiles; cur_tile += G) {
-    const bool n_ok = (cur_tile >> 3) * 128 + (cur_tile & 7) * 4 + cm_rowpart < p.N;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int cur_slab = 0; cur_slab < nslabs; ++cur_slab) {
-      unsigned char* buf = smem + parity * lds_buf;
-      parity ^= 1;
-      *reinterpret_cast<uint4*>(buf + wrb_off) = r0.b;
-      if (a_loader) {
-        // dequantise this thread's 32 activations once for the whole workgroup (cost scales with M, not 16)
-        const uint32_t sa = ld_atom + cur_slab * kSlabAtoms < atoms_k ? r0.sa : 0u;
-        const f16x2 s0 = sf_pair(sa & 0xffu), s1 = sf_pair((sa >> 8) & 0xffu);
-        Frag8 f0 = dequant8(r0.a.x, s0), f1 = dequant8(r0.a.y, s0), f2 = dequant8(r0.a.z, s1), f3 = dequant8(r0.a.w, s1);
-        *reinterpret_cast<uint4*>(buf + wra_off + ((0 ^ wra_swz) << 4)) = f0.u;
-        *reinterpret_cast<uint4*>(buf + wra_off + ((1 ^ wra_swz) << 4)) = f1.u;
-        *reinterpret_cast<uint4*>(buf + wra_off + ((2 ^ wra_swz) << 4)) = f2.u;
-        *reinterpret_cast<uint4*>(buf + wra_off + ((3 ^ wra_swz) << 4)) = f3.u;
-      }
-      uint32_t bs = r0.sb;
-      r0 = r1;                                                 // advance the ring ...
-      r1 = r2;
-      issue_next(r2);                                          // ... and refill its tail: kRing items ahead
-      __syncthreads();
-      if (tr && tid == 0 && first) { tr[2] = wall_clock64(); first = false; }
-      const bool live = lane_atom + cur_slab * kSlabAtoms < atoms_k;   // false only in the partial tail slab
-      bs = (live && n_ok) ? bs : 0u;
-      const uint4 bq = *reinterpret_cast<const uint4*>(buf + rdb_off);
-      Frag8 a0, a1, a2, a3;
-      a0.u = *reinterpret_cast<const uint4*>(buf + rda_off + ((0 ^ rda_swz) << 4));
-      a1.u = *reinterpret_cast<const uint4*>(buf + rda_off + ((1 ^ rda_swz) << 4));
-      a2.u = *reinterpret_cast<const uint4*>(buf + rda_off + ((2 ^ rda_swz) << 4));
-      a3.u = *reinterpret_cast<const uint4*>(buf + rda_off + ((3 ^ rda_swz) << 4));
-      const f16x2 sb0 = sf_pair((bs >> sh) & 0xffu), sb1 = sf_pair((bs >> (sh + 8)) & 0xffu);
-      Frag8 b0 = dequant8(bq.x, sb0), b1 = dequant8(bq.y, sb0), b2 = dequant8(bq.z, sb1), b3 = dequant8(bq.w, sb1);
-      // weights are the MFMA A operand (rows i = rho), activations the B operand (cols j = token)
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0.v, a0.v, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1.v, a1.v, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b2.v, a2.v, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b3.v, a3.v, acc, 0, 0, 0);
+  // One item: stage `r` into LDS, refill `r` with the item three ahead, barrier, multiply; close the tile after
+  // its last slab (cross-wave reduction through LDS, fused epilogue).
+  auto step = [&](ItemRegs& r) {
+    unsigned char* buf = smem + parity * lds_buf;
+    parity ^= 1;
+    *reinterpret_cast<uint4*>(buf + wrb_off) = r.b;
+    if (a_loader) {
+      // dequantise this thread's 32 activations once for the whole workgroup (cost scales with M, not 16)
+      const uint32_t sa = ld_atom + cur_slab * kSlabAtoms < atoms_k ? (r.sa >> ((ld_u & 1) * 16)) : 0u;
+      const f16x2 s0 = sf_pair(sa & 0xffu), s1 = sf_pair((sa >> 8) & 0xffu);
+      Frag8 f0 = dequant8(r.a.x, s0), f1 = dequant8(r.a.y, s0), f2 = dequant8(r.a.z, s1), f3 = dequant8(r.a.w, s1);
+      *reinterpret_cast<uint4*>(buf + wra_off + ((0 ^ wra_swz) << 4)) = f0.u;
+      *reinterpret_cast<uint4*>(buf + wra_off + ((1 ^ wra_swz) << 4)) = f1.u;
+      *reinterpret_cast<uint4*>(buf + wra_off + ((2 ^ wra_swz) << 4)) = f2.u;
+      *reinterpret_cast<uint4*>(buf + wra_off + ((3 ^ wra_swz) << 4)) = f3.u;
     }
-    if (tr && tid == 0 && cur_tile + G >= p.tiles) tr[3] = wall_clock64();
-
-    // ---- tile done: cross-wave reduction; lane holds C[rho = 4q + r][token = rl]
-#pragma unroll
-    for (int r = 0; r < 4; ++r) red[(wave * 64 + lane) * 4 + r] = acc[r];
+    uint32_t bs = r.sb;
+    issue_next(r);                                             // refill: kRing = 3 items ahead
     __syncthreads();
-    if (wave == 0) {
-      float sum[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool n_ok = (cur_tile >> 3) * 128 + (cur_tile & 7) * 4 + cm_rowpart < p.N;
+    const bool live = lane_atom + cur_slab * kSlabAtoms < atoms_k;   // false only in the partial tail slab
+    bs = (live && n_ok) ? bs : 0u;
+    const uint4 bq = *reinterpret_cast<const uint4*>(buf + rdb_off);
+    Frag8 a0, a1, a2, a3;
+    a0.u = *reinterpret_cast<const uint4*>(buf + rda_off + ((0 ^ rda_swz) << 4));
+    a1.u = *reinterpret_cast<const uint4*>(buf + rda_off + ((1 ^ rda_swz) << 4));
+    a2.u = *reinterpret_cast<const uint4*>(buf + rda_off + ((2 ^ rda_swz) << 4));
+    a3.u = *reinterpret_cast<const uint4*>(buf + rda_off + ((3 ^ rda_swz) << 4));
+    const f16x2 sb0 = sf_pair((bs >> sh) & 0xffu), sb1 = sf_pair((bs >> (sh + 8)) & 0xffu);
+    Frag8 b0 = dequant8(bq.x, sb0), b1 = dequant8(bq.y, sb0), b2 = dequant8(bq.z, sb1), b3 = dequant8(bq.w, sb1);
+    // weights are the MFMA A operand (rows i = rho), activations the B operand (cols j = token)
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0.v, a0.v, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1.v, a1.v, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b2.v, a2.v, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b3.v, a3.v, acc, 0, 0, 0);
+    if (++cur_slab == nslabs) {                                // wave-uniform
+      // ---- tile done: cross-wave reduction; lane holds C[rho = 4q + r][token = rl]
 #pragma unroll
-      for (int w = 0; w < kSkWaves; ++w) {
-        const float4 v = *reinterpret_cast<const float4*>(red + (w * 64 + lane) * 4);
-        sum[0] += v.x; sum[1] += v.y; sum[2] += v.z; sum[3] += v.w;
-      }
-      const int nn = (cur_tile >> 3) * 128 + (cur_tile & 7) * 4 + q * 32;   // rho = 4q + r -> 4 consecutive columns
-      if (m_ok && nn < p.N) {
-        if (gridDim.y == 1) {
-          finish4(p, rl, nn, sum);
-        } else {
-          float* o = p.partial + ((size_t)blockIdx.y * p.M + rl) * p.N + nn;
-          for (int r = 0; r < 4; ++r) if (nn + r < p.N) o[r] = sum[r];
+      for (int e = 0; e < 4; ++e) red[(wave * 64 + lane) * 4 + e] = acc[e];
+      __syncthreads();
+      if (wave == 0) {
+        float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < kSkWaves; ++w) {
+          const float4 v = *reinterpret_cast<const float4*>(red + (w * 64 + lane) * 4);
+          sum[0] += v.x; sum[1] += v.y; sum[2] += v.z; sum[3] += v.w;
+        }
+        const int nn = (cur_tile >> 3) * 128 + (cur_tile & 7) * 4 + q * 32;   // rho = 4q + r -> 4 consecutive columns
+        if (m_ok && nn < p.N) {
+          if (gridDim.y == 1) {
+            finish4<uint32_t>(p, alpha, rl, nn, sum);
+          } else {
+            float* o = p.partial + ((uint32_t)(blockIdx.y * p.M + rl) * (uint32_t)p.N + (uint32_t)nn);
+            for (int e = 0; e < 4; ++e) if (nn + e < p.N) o[e] = sum[e];
+          }
         }
       }
+      // `red` is next written after at least one more __syncthreads (the next tile's first item), so no barrier here
+      cur_slab = 0;
+      cur_tile += G;
+      acc = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if (tr && tid == 0 && cur_tile + G >= p.tiles) tr[4] = wall_clock64();
-    // `red` is next written after at least one more __syncthreads (the next tile's first item), so no barrier here
-  }
-}
+  };
 
-void* g_trace_buf = nullptr;   // set by arcq_debug_set_trace
+  int it = 0;
+#pragma unroll 1
+  for (; it + 3 <= nitems; it += 3) {
+    step(r0);
+    step(r1);
+    step(r2);
+  }
+  if (it < nitems) step(r0);
+  if (it + 1 < nitems) step(r1);
+}
 
 // second pass of split-K: D[m,n] = epilogue(sum_s partial[s,m,n]) in a fixed order (deterministic)
 __global__ __launch_bounds__(256) void splitk_finish_kernel(SkinnyParams p, int splitk) {
@@ -294,7 +300,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(SkinnyParams p, int 
     const float4 v = *reinterpret_cast<const float4*>(p.partial + (size_t)k * total + i4);
     s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
   }
-  finish4(p, m, n, s);
+  finish4<size_t>(p, p.alpha_host * (p.alpha_dev ? *p.alpha_dev : 1.0f), m, n, s);
 }
 
 int gemm_splitk_finish(const GemmArgs& a, int splitk, hipStream_t stream) {
@@ -370,7 +376,6 @@ int gemm_skinny(const GemmArgs& a, hipStream_t stream) {
   p.M = a.M; p.N = a.N; p.K = a.K; p.alpha_host = a.alpha_host; p.out_dtype = a.out_dtype;
   p.tiles = ((a.N + 127) / 128) * 8;
   p.slabs_per_split = per;
-  p.trace = reinterpret_cast<unsigned long long*>(g_trace_buf);
   if (splitk > 1) {
     const int64_t need = (int64_t)splitk * a.M * a.N * (int64_t)sizeof(float);
     if (!a.workspace || a.workspace_bytes < need)

@@ -121,11 +121,6 @@ int arcq_absmax_scale(const void *X, int64_t n, float *scale_out, void *stream);
 int arcq_quantize_x_dyn(const void *X, const int16_t *reorder_index, uint8_t *QX, uint8_t *SFX, float *scale_out,
                         void *state, int64_t M, int64_t KQ, int64_t KE, int variant, void *stream);
 
-/* ---- debug (tuning only): the decode GEMM writes 8 x u64 wall-clock (100 MHz) stamps per workgroup into
- *      dev_buf while it is non-NULL: [0] start, [1] prefetch issued, [2] first item landed, [3] last item
- *      multiplied, [4] last tile stored. */
-int arcq_debug_set_trace(void *dev_buf);
-
 #ifdef __cplusplus
 }
 #endif
