@@ -41,7 +41,9 @@ int64_t gemm_skinny_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int64_t gemm_tile_workspace_bytes(int64_t M, int64_t N, int64_t K);
 // D = epilogue(sum_s partial[s]) over the `splitk` fp32 planes [M, N] at a.workspace, summed in a fixed order
 int gemm_splitk_finish(const GemmArgs& a, int splitk, hipStream_t stream);
-int gemm_skinny(const GemmArgs& a, hipStream_t stream);   // M <= 16: weight-streaming MFMA GEMV
+int gemm_skinny(const GemmArgs& a, hipStream_t stream);   // M <= 16, few tiles: weight-streaming MFMA GEMV, 16-row tiles
+int64_t gemm_decode_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int gemm_decode(const GemmArgs& a, hipStream_t stream);   // M <= 16, many tiles: 32-row tiles, two units per thread and item
 int gemm_tile(const GemmArgs& a, hipStream_t stream);     // general M: LDS-tiled MFMA GEMM
 
 }  // namespace arcq

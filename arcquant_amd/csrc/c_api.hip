@@ -79,9 +79,19 @@ int arcq_absmax_scale(const void* X, int64_t n, float* scale_out, void* stream) 
 
 static const int64_t kSkinnyMaxM = 16;
 
+// M <= 16: the 32-row-tile kernel needs enough tiles to occupy the chip without split-K (its tiles are twice as
+// tall); below that the 16-row-tile kernel wins.  ARCQ_DECODE=1|2 forces the first / second generation (tuning).
+static bool use_decode_v2(int64_t N) {
+  static const int forced = getenv("ARCQ_DECODE") ? atoi(getenv("ARCQ_DECODE")) : 0;
+  if (forced == 1) return false;
+  if (forced == 2) return true;
+  return ((N + 127) / 128) * 4 >= 256;
+}
+
 int64_t arcq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  return M <= kSkinnyMaxM ? gemm_skinny_workspace_bytes(M, N, K) : gemm_tile_workspace_bytes(M, N, K);
+  if (M <= kSkinnyMaxM) return use_decode_v2(N) ? gemm_decode_workspace_bytes(M, N, K) : gemm_skinny_workspace_bytes(M, N, K);
+  return gemm_tile_workspace_bytes(M, N, K);
 }
 
 int arcq_gemm_nvfp4(const uint8_t* A, const uint8_t* B, const uint8_t* SFA, const uint8_t* SFB, void* D, int64_t M, int64_t N,
@@ -104,7 +114,7 @@ int arcq_gemm_nvfp4(const uint8_t* A, const uint8_t* B, const uint8_t* SFA, cons
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.alpha_host = alpha_host; a.alpha_dev = alpha_dev; a.bias = (const uint16_t*)bias; a.residual = (const uint16_t*)residual; a.out_dtype = out_dtype;
   a.workspace = workspace; a.workspace_bytes = workspace_bytes;
-  if (M <= kSkinnyMaxM) return gemm_skinny(a, (hipStream_t)stream);
+  if (M <= kSkinnyMaxM) return use_decode_v2(N) ? gemm_decode(a, (hipStream_t)stream) : gemm_skinny(a, (hipStream_t)stream);
   return gemm_tile(a, (hipStream_t)stream);
 }
 

@@ -63,4 +63,42 @@ __device__ __forceinline__ int64_t sf_atom_offset(int r, int atom, int atoms_k) 
 // alpha*acc (+bias) -> bf16 / fp32 store helpers
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) { return f32_to_bf16_bits(a) | (f32_to_bf16_bits(b) << 16); }
 
+// Epilogue helpers shared by the GEMM kernels; P is any parameter block with D, N, bias, residual, out_dtype.
+// Idx = uint32_t inside the decode kernel (M <= 16: element offsets fit 32 bits, so the address is an SGPR base
+// plus one VGPR offset instead of a 64-bit VGPR pair per lane -- the kernel is register bound), size_t elsewhere.
+template <typename Idx, typename P>
+__device__ __forceinline__ void store_out4(const P& p, int m, int n, const float (&d)[4]) {
+  // d[r] is the finished value of D[m, n + r]
+  if (p.out_dtype == ARCQ_OUT_F32) {
+    float* o = reinterpret_cast<float*>(p.D) + ((Idx)m * (Idx)p.N + (Idx)n);
+    if (n + 3 < p.N && (p.N & 3) == 0) {
+      *reinterpret_cast<float4*>(o) = make_float4(d[0], d[1], d[2], d[3]);
+    } else {
+      for (int r = 0; r < 4; ++r) if (n + r < p.N) o[r] = d[r];
+    }
+  } else {
+    uint16_t* o = reinterpret_cast<uint16_t*>(p.D) + ((Idx)m * (Idx)p.N + (Idx)n);
+    if (n + 3 < p.N && (p.N & 3) == 0) {
+      *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3]));
+    } else {
+      for (int r = 0; r < 4; ++r) if (n + r < p.N) o[r] = (uint16_t)f32_to_bf16_bits(d[r]);
+    }
+  }
+}
+
+template <typename Idx, typename P>
+__device__ __forceinline__ void finish4(const P& p, float alpha, int m, int n, const float (&acc)[4]) {
+  float d[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    d[r] = alpha * acc[r];                                          // epilogue in fp32 (nvfp4.cu:117-121)
+    if (p.bias && n + r < p.N) d[r] += bf16_bits_to_f32(p.bias[n + r]);
+    if (p.residual && n + r < p.N) {
+      const float res = bf16_bits_to_f32(p.residual[(Idx)m * (Idx)p.N + (Idx)(n + r)]);
+      d[r] = (p.out_dtype == ARCQ_OUT_F32 ? d[r] : bf16_bits_to_f32(f32_to_bf16_bits(d[r]))) + res;
+    }
+  }
+  store_out4<Idx>(p, m, n, d);
+}
+
 }  // namespace arcq

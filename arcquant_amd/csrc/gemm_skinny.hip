@@ -1,17 +1,21 @@
-// ARC-NVFP4 GEMM for decode shapes (M <= 16): a weight-streaming, HBM-bound kernel for gfx950.
+// ARC-NVFP4 GEMM for decode shapes (M <= 16) with FEW weight tiles (N < 8192): the latency-bound member of the
+// decode pair (gemm_decode.hip is the throughput-bound one; c_api.hip picks).
 //
 // Replaces the CUTLASS 128x128x128 block-scaled GEMM of the reference (kernels/src/nvfp4.cu:35-132)
 // for the shapes where that kernel leaves 127/128 of its M tile empty ("decode").
 //
 // Roofline: bytes per launch = N*K*9/16 (packed B + scale bytes) + M*K*9/16 + M*N*2; everything else is
 // on-chip.  Measured floor for ONE short kernel that only reads that many bytes (tools/probe_stream.hip):
-// 9.6 MB -> 3.3 us, 33.5 MB -> 6.5 us.  Design for that bound:
-//   * persistent workgroups (8 wave64); a workgroup walks "items" = (tile of 16 weight rows, slab of 1024
-//     K elements).  Per item every thread fetches exactly ONE 16-byte unit of packed B with a plain
-//     global_load_dwordx4: a wave covers two 512-byte row segments (full lines; the first version loaded B
-//     straight into the MFMA operand layout, 16 rows x 64 B per instruction, and its loads alone took as
-//     long as the whole kernel).  A 6-deep REGISTER ring keeps six items in flight across tile boundaries,
-//     so HBM latency is paid once per workgroup, not once per tile
+// 9.6 MB -> 3.3 us, 33.5 MB -> 6.5 us.  At these sizes a workgroup sees 2-5 items in its whole life, so what
+// counts is the start-up path (cold instruction cache, first HBM round trip), not steady-state issue rate:
+//   * persistent workgroups (8 or 16 wave64); a workgroup walks "items" = (tile of 16 weight rows, slab of
+//     kWaves*128 K elements).  Per item every thread fetches exactly ONE 16-byte unit of packed B with a plain
+//     global_load_dwordx4: a wave covers two 512-byte row segments (full lines; loading B straight into the
+//     MFMA operand layout, 16 rows x 64 B per instruction, reaches only 0.6-3.8 TB/s: tools/probe_rows.hip).
+//     Three items are requested before the first is used; the item loop is ROLLED (ring rotated by moves) to
+//     keep the code small -- the rotation makes hipcc wait for the youngest load, which costs steady-state
+//     depth this kernel does not live long enough to use (the unrolled, exactly-counted ring of gemm_decode.hip
+//     measured 5.9 -> 6.7 us here on N=K=3584 and wins only from N = 8192 up)
 //   * the packed bytes are transposed into the MFMA operand layout through a small double-buffered LDS
 //     image (padded rows: conflict-free), one barrier per item
 //   * a tile's 16 rows are {32j + 4t + i} of a 128-row super-tile: their scale bytes then fill whole
@@ -47,43 +51,6 @@ struct SkinnyParams {
   int slabs_per_split;
 };
 
-// Idx = uint32_t inside the decode kernel (M <= 16: element offsets fit 32 bits, so the address is an SGPR base
-// plus one VGPR offset instead of a 64-bit VGPR pair per lane -- the kernel is register bound), size_t elsewhere.
-template <typename Idx>
-__device__ __forceinline__ void store_out4(const SkinnyParams& p, int m, int n, const float (&d)[4]) {
-  // d[r] is the finished value of D[m, n + r]
-  if (p.out_dtype == ARCQ_OUT_F32) {
-    float* o = reinterpret_cast<float*>(p.D) + ((Idx)m * (Idx)p.N + (Idx)n);
-    if (n + 3 < p.N && (p.N & 3) == 0) {
-      *reinterpret_cast<float4*>(o) = make_float4(d[0], d[1], d[2], d[3]);
-    } else {
-      for (int r = 0; r < 4; ++r) if (n + r < p.N) o[r] = d[r];
-    }
-  } else {
-    uint16_t* o = reinterpret_cast<uint16_t*>(p.D) + ((Idx)m * (Idx)p.N + (Idx)n);
-    if (n + 3 < p.N && (p.N & 3) == 0) {
-      *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3]));
-    } else {
-      for (int r = 0; r < 4; ++r) if (n + r < p.N) o[r] = (uint16_t)f32_to_bf16_bits(d[r]);
-    }
-  }
-}
-
-template <typename Idx>
-__device__ __forceinline__ void finish4(const SkinnyParams& p, float alpha, int m, int n, const float (&acc)[4]) {
-  float d[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    d[r] = alpha * acc[r];                                          // epilogue in fp32 (nvfp4.cu:117-121)
-    if (p.bias && n + r < p.N) d[r] += bf16_bits_to_f32(p.bias[n + r]);
-    if (p.residual && n + r < p.N) {
-      const float res = bf16_bits_to_f32(p.residual[(Idx)m * (Idx)p.N + (Idx)(n + r)]);
-      d[r] = (p.out_dtype == ARCQ_OUT_F32 ? d[r] : bf16_bits_to_f32(f32_to_bf16_bits(d[r]))) + res;
-    }
-  }
-  store_out4<Idx>(p, m, n, d);
-}
-
 // A workgroup of kWaves wave64 walks items of kWaves*128 K elements: one 16-byte unit per thread (loader role), one
 // 128-element MFMA chunk per wave (compute role).  kWaves = 16 (1024 threads, 2048-element items) halves the number
 // of barriers per byte and doubles the waves that hide each other's latencies; its fp16 A image only fits for M <= 8.
@@ -105,7 +72,7 @@ struct SkinnyCfg {
 struct ItemRegs {
   uint4 b;             // loader role: this thread's 16-byte unit of packed B
   uint4 a;             // loader role (token rows only): 16-byte unit of packed A
-  uint32_t sa;         // ... and the four scale bytes of its atom (the unit uses two of them)
+  uint32_t sa;         // ... and the two scale bytes of that unit
   uint32_t sb;         // compute role: this lane's 4 scale bytes (one atom) of B for its wave's chunk
 };
 
@@ -138,8 +105,7 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gemm_skinny_kernel(SkinnyParam
   const bool m_ok = rl < p.M;
   const bool a_loader = ld_rho < p.M;
 
-  // read before the ring starts: a load consumed inside the item loop would have to wait for every ring load
-  // issued before it (vmcnt is an in-order counter)
+  // read before the ring starts: a load consumed inside the item loop would wait for every ring load before it
   const float alpha = p.alpha_host * (p.alpha_dev ? *p.alpha_dev : 1.0f);
 
   // A tile's 16 rows are {128*T + 32*j + 4*t + i}: rho = 4j + i
@@ -149,8 +115,8 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gemm_skinny_kernel(SkinnyParam
   const uint32_t k_last = half_k - 16u;                                        // clamp for the partial tail slab
   const uint32_t sfb_lane = (rl & 3) * 16 + (rl >> 2) * 4 + (2 * wave + (q >> 1)) * 512 + (uint32_t)slab_begin * kSlabAtoms * 512u;
   const uint32_t sfb_small = (rl & 3) * 16 + (rl >> 2) * 4;
-  const uint32_t sfa_first = (uint32_t)ld_rho * 16 + ((uint32_t)slab_begin * kSlabAtoms + (ld_u >> 1)) * 512u;   // the atom's aligned dword
-  const uint32_t sfa_last = (uint32_t)ld_rho * 16 + (uint32_t)(atoms_k - 1) * 512u;
+  const uint32_t sfa_first = (uint32_t)ld_rho * 16 + ((uint32_t)slab_begin * kSlabAtoms + (ld_u >> 1)) * 512u + (ld_u & 1) * 2;
+  const uint32_t sfa_last = (uint32_t)ld_rho * 16 + (uint32_t)(atoms_k - 1) * 512u + (ld_u & 1) * 2;
 
   // ---- issue side state (runs kRing items ahead of the compute side); all offsets are carried incrementally
   int iss_tile = blockIdx.x, iss_slab = 0, issued = 0;
@@ -163,18 +129,17 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gemm_skinny_kernel(SkinnyParam
   };
   issue_tile_setup();
   uint32_t k_cur = k_first, sfb_cur = sfb_lane, sfa_cur = sfa_first;
-  const uint32_t a_row = (uint32_t)min(ld_rho, p.M - 1) * half_k;        // token rows >= M duplicate the last one (never stored)
-  // Every thread issues the SAME loads for every item (rows clamped, nothing predicated): only then can the
-  // compiler count them and wait with vmcnt(N) for the oldest item while the younger ones stay in flight -- with
-  // predicated loads it falls back to vmcnt(0) and the ring collapses to one item.  The cursor stops at the last
-  // item, so the ring's final refills re-read valid memory.
+  const uint32_t a_row = (uint32_t)ld_rho * half_k;
   auto issue_next = [&](ItemRegs& r) {
-    const uint32_t koff = min(k_cur, k_last);
-    r.b = *reinterpret_cast<const uint4*>(p.B + (size_t)(b_row + koff));
-    r.sb = *reinterpret_cast<const uint32_t*>(p.SFB + (size_t)min(sfb_row + sfb_cur, sfb_rowmax));
-    r.a = *reinterpret_cast<const uint4*>(p.A + (size_t)(a_row + koff));
-    r.sa = *reinterpret_cast<const uint32_t*>(p.SFA + (size_t)min(sfa_cur, sfa_last));   // dword: a 16-bit load is widened at once, i.e. waited for
-    if (issued + 1 < nitems) {                                 // wave-uniform, address arithmetic only
+    if (issued < nitems) {                                     // wave-uniform
+      const uint32_t koff = min(k_cur, k_last);
+      r.b = *reinterpret_cast<const uint4*>(p.B + (size_t)(b_row + koff));
+      r.sb = *reinterpret_cast<const uint32_t*>(p.SFB + (size_t)min(sfb_row + sfb_cur, sfb_rowmax));
+      if (a_loader) {
+        r.a = *reinterpret_cast<const uint4*>(p.A + (size_t)(a_row + koff));
+        r.sa = *reinterpret_cast<const uint16_t*>(p.SFA + (size_t)min(sfa_cur, sfa_last));
+      }
+      ++issued;
       k_cur += kSlabBytes; sfb_cur += kSlabAtoms * 512u; sfa_cur += kSlabAtoms * 512u;
       if (++iss_slab == nslabs) {
         iss_slab = 0; iss_tile += G;
@@ -182,12 +147,14 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gemm_skinny_kernel(SkinnyParam
         issue_tile_setup();
       }
     }
-    ++issued;
   };
 
-  // The register ring is addressed BY NAME (the item loop is unrolled three times): rotating it with moves would
-  // read the registers of the youngest load and so wait for it, collapsing the ring to a single item in flight.
+  // Code size matters more than steady-state depth here: every launch starts with a cold instruction cache and
+  // most of this kernel runs exactly once per workgroup, so the item loop is ROLLED (the register ring advances
+  // by moves instead of by unrolling) and the per-tile epilogue exists once.
   ItemRegs r0, r1, r2;
+  r0.b = r0.a = r1.b = r1.a = r2.b = r2.a = make_uint4(0, 0, 0, 0);
+  r0.sb = r0.sa = r1.sb = r1.sa = r2.sb = r2.sa = 0;
   issue_next(r0);
   issue_next(r1);
   issue_next(r2);
@@ -211,82 +178,71 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gemm_skinny_kernel(SkinnyParam
   const int lane_atom = slab_begin * kSlabAtoms + 2 * wave + (q >> 1);   // compute role: atom of slab 0
   const int ld_atom = slab_begin * kSlabAtoms + (ld_u >> 1);             // loader role (A): atom of slab 0
   int parity = 0;
-  int cur_tile = blockIdx.x, cur_slab = 0;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 
-  // One item: stage `r` into LDS, refill `r` with the item three ahead, barrier, multiply; close the tile after
-  // its last slab (cross-wave reduction through LDS, fused epilogue).
-  auto step = [&](ItemRegs& r) {
-    unsigned char* buf = smem + parity * lds_buf;
-    parity ^= 1;
-    *reinterpret_cast<uint4*>(buf + wrb_off) = r.b;
-    if (a_loader) {
-      // dequantise this thread's 32 activations once for the whole workgroup (cost scales with M, not 16)
-      const uint32_t sa = ld_atom + cur_slab * kSlabAtoms < atoms_k ? (r.sa >> ((ld_u & 1) * 16)) : 0u;
-      const f16x2 s0 = sf_pair(sa & 0xffu), s1 = sf_pair((sa >> 8) & 0xffu);
-      Frag8 f0 = dequant8(r.a.x, s0), f1 = dequant8(r.a.y, s0), f2 = dequant8(r.a.z, s1), f3 = dequant8(r.a.w, s1);
-      *reinterpret_cast<uint4*>(buf + wra_off + ((0 ^ wra_swz) << 4)) = f0.u;
-      *reinterpret_cast<uint4*>(buf + wra_off + ((1 ^ wra_swz) << 4)) = f1.u;
-      *reinterpret_cast<uint4*>(buf + wra_off + ((2 ^ wra_swz) << 4)) = f2.u;
-      *reinterpret_cast<uint4*>(buf + wra_off + ((3 ^ wra_swz) << 4)) = f3.u;
-    }
-    uint32_t bs = r.sb;
-    issue_next(r);                                             // refill: kRing = 3 items ahead
-    __syncthreads();
+#pragma unroll 1
+  for (int cur_tile = blockIdx.x; cur_tile < p.tiles; cur_tile += G) {
     const bool n_ok = (cur_tile >> 3) * 128 + (cur_tile & 7) * 4 + cm_rowpart < p.N;
-    const bool live = lane_atom + cur_slab * kSlabAtoms < atoms_k;   // false only in the partial tail slab
-    bs = (live && n_ok) ? bs : 0u;
-    const uint4 bq = *reinterpret_cast<const uint4*>(buf + rdb_off);
-    Frag8 a0, a1, a2, a3;
-    a0.u = *reinterpret_cast<const uint4*>(buf + rda_off + ((0 ^ rda_swz) << 4));
-    a1.u = *reinterpret_cast<const uint4*>(buf + rda_off + ((1 ^ rda_swz) << 4));
-    a2.u = *reinterpret_cast<const uint4*>(buf + rda_off + ((2 ^ rda_swz) << 4));
-    a3.u = *reinterpret_cast<const uint4*>(buf + rda_off + ((3 ^ rda_swz) << 4));
-    const f16x2 sb0 = sf_pair((bs >> sh) & 0xffu), sb1 = sf_pair((bs >> (sh + 8)) & 0xffu);
-    Frag8 b0 = dequant8(bq.x, sb0), b1 = dequant8(bq.y, sb0), b2 = dequant8(bq.z, sb1), b3 = dequant8(bq.w, sb1);
-    // weights are the MFMA A operand (rows i = rho), activations the B operand (cols j = token)
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0.v, a0.v, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1.v, a1.v, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b2.v, a2.v, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b3.v, a3.v, acc, 0, 0, 0);
-    if (++cur_slab == nslabs) {                                // wave-uniform
-      // ---- tile done: cross-wave reduction; lane holds C[rho = 4q + r][token = rl]
-#pragma unroll
-      for (int e = 0; e < 4; ++e) red[(wave * 64 + lane) * 4 + e] = acc[e];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int cur_slab = 0; cur_slab < nslabs; ++cur_slab) {
+      unsigned char* buf = smem + parity * lds_buf;
+      parity ^= 1;
+      *reinterpret_cast<uint4*>(buf + wrb_off) = r0.b;
+      if (a_loader) {
+        // dequantise this thread's 32 activations once for the whole workgroup (cost scales with M, not 16)
+        const uint32_t sa = ld_atom + cur_slab * kSlabAtoms < atoms_k ? r0.sa : 0u;
+        const f16x2 s0 = sf_pair(sa & 0xffu), s1 = sf_pair((sa >> 8) & 0xffu);
+        Frag8 f0 = dequant8(r0.a.x, s0), f1 = dequant8(r0.a.y, s0), f2 = dequant8(r0.a.z, s1), f3 = dequant8(r0.a.w, s1);
+        *reinterpret_cast<uint4*>(buf + wra_off + ((0 ^ wra_swz) << 4)) = f0.u;
+        *reinterpret_cast<uint4*>(buf + wra_off + ((1 ^ wra_swz) << 4)) = f1.u;
+        *reinterpret_cast<uint4*>(buf + wra_off + ((2 ^ wra_swz) << 4)) = f2.u;
+        *reinterpret_cast<uint4*>(buf + wra_off + ((3 ^ wra_swz) << 4)) = f3.u;
+      }
+      uint32_t bs = r0.sb;
+      r0 = r1;                                                 // advance the ring ...
+      r1 = r2;
+      issue_next(r2);                                          // ... and refill its tail: kRing items ahead
       __syncthreads();
-      if (wave == 0) {
-        float sum[4] = {0.f, 0.f, 0.f, 0.f};
+      const bool live = lane_atom + cur_slab * kSlabAtoms < atoms_k;   // false only in the partial tail slab
+      bs = (live && n_ok) ? bs : 0u;
+      const uint4 bq = *reinterpret_cast<const uint4*>(buf + rdb_off);
+      Frag8 a0, a1, a2, a3;
+      a0.u = *reinterpret_cast<const uint4*>(buf + rda_off + ((0 ^ rda_swz) << 4));
+      a1.u = *reinterpret_cast<const uint4*>(buf + rda_off + ((1 ^ rda_swz) << 4));
+      a2.u = *reinterpret_cast<const uint4*>(buf + rda_off + ((2 ^ rda_swz) << 4));
+      a3.u = *reinterpret_cast<const uint4*>(buf + rda_off + ((3 ^ rda_swz) << 4));
+      const f16x2 sb0 = sf_pair((bs >> sh) & 0xffu), sb1 = sf_pair((bs >> (sh + 8)) & 0xffu);
+      Frag8 b0 = dequant8(bq.x, sb0), b1 = dequant8(bq.y, sb0), b2 = dequant8(bq.z, sb1), b3 = dequant8(bq.w, sb1);
+      // weights are the MFMA A operand (rows i = rho), activations the B operand (cols j = token)
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0.v, a0.v, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1.v, a1.v, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b2.v, a2.v, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b3.v, a3.v, acc, 0, 0, 0);
+    }
+
+    // ---- tile done: cross-wave reduction; lane holds C[rho = 4q + r][token = rl]
 #pragma unroll
-        for (int w = 0; w < kSkWaves; ++w) {
-          const float4 v = *reinterpret_cast<const float4*>(red + (w * 64 + lane) * 4);
-          sum[0] += v.x; sum[1] += v.y; sum[2] += v.z; sum[3] += v.w;
-        }
-        const int nn = (cur_tile >> 3) * 128 + (cur_tile & 7) * 4 + q * 32;   // rho = 4q + r -> 4 consecutive columns
-        if (m_ok && nn < p.N) {
-          if (gridDim.y == 1) {
-            finish4<uint32_t>(p, alpha, rl, nn, sum);
-          } else {
-            float* o = p.partial + ((uint32_t)(blockIdx.y * p.M + rl) * (uint32_t)p.N + (uint32_t)nn);
-            for (int e = 0; e < 4; ++e) if (nn + e < p.N) o[e] = sum[e];
-          }
+    for (int r = 0; r < 4; ++r) red[(wave * 64 + lane) * 4 + r] = acc[r];
+    __syncthreads();
+    if (wave == 0) {
+      float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < kSkWaves; ++w) {
+        const float4 v = *reinterpret_cast<const float4*>(red + (w * 64 + lane) * 4);
+        sum[0] += v.x; sum[1] += v.y; sum[2] += v.z; sum[3] += v.w;
+      }
+      const int nn = (cur_tile >> 3) * 128 + (cur_tile & 7) * 4 + q * 32;   // rho = 4q + r -> 4 consecutive columns
+      if (m_ok && nn < p.N) {
+        if (gridDim.y == 1) {
+          finish4<uint32_t>(p, alpha, rl, nn, sum);
+        } else {
+          float* o = p.partial + ((uint32_t)(blockIdx.y * p.M + rl) * (uint32_t)p.N + (uint32_t)nn);
+          for (int r = 0; r < 4; ++r) if (nn + r < p.N) o[r] = sum[r];
         }
       }
-      // `red` is next written after at least one more __syncthreads (the next tile's first item), so no barrier here
-      cur_slab = 0;
-      cur_tile += G;
-      acc = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-  };
-
-  int it = 0;
-#pragma unroll 1
-  for (; it + 3 <= nitems; it += 3) {
-    step(r0);
-    step(r1);
-    step(r2);
+    // `red` is next written after at least one more __syncthreads (the next tile's first item), so no barrier here
   }
-  if (it < nitems) step(r0);
-  if (it + 1 < nitems) step(r1);
 }
 
 // second pass of split-K: D[m,n] = epilogue(sum_s partial[s,m,n]) in a fixed order (deterministic)
@@ -315,13 +271,15 @@ int gemm_splitk_finish(const GemmArgs& a, int splitk, hipStream_t stream) {
   return ARCQ_OK;
 }
 
-// split-K (over whole items) only when the tiles alone leave most CUs idle
+// split-K (over whole items) only when the tiles alone leave most CUs idle AND every split keeps >= 8 items: the
+// second pass costs a launch (~5 us in a graph), more than a short serial K loop (N=1024 K=4160: 14.3 us split,
+// measured, against ~7 us for the same per-workgroup work unsplit)
 static void choose_split(int64_t N, int64_t K, int slab_k, int* splitk, int* slabs_per_split) {
   const int64_t tiles = ((N + 127) / 128) * 8;
   const int nslabs = (int)((K + slab_k - 1) / slab_k);
   int s = 1;
   if ((N % 4) == 0) {
-    while (tiles * s < 192 && s * 2 <= nslabs && s < 16) s *= 2;
+    while (tiles * s < 192 && nslabs / (s * 2) >= 8 && s < 16) s *= 2;
   }
   int per = (nslabs + s - 1) / s;
   s = (nslabs + per - 1) / per;          // drop empty splits
