@@ -35,6 +35,7 @@ SYMBOLS = {
     "arcq_gemm_nvfp4": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _f32, _p, _p, _p, _i32, _p, _i64, _p]),
     "arcq_absmax_scale": (_i32, [_p, _i64, _p, _p]),
     "arcq_quantize_x_dyn": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p]),
+    "arcq_silu_mul_quantize_x_dyn": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p]),
 }
 
 _lib = None

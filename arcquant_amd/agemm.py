@@ -175,19 +175,15 @@ def absmax_scale(X: torch.Tensor) -> torch.Tensor:
 _dyn_state = {}
 
 
-def reorder_quantize_x_dynamic(X: torch.Tensor, reorder_index: torch.Tensor, KE: int, variant=None):
-    """Extension: ``NVFP4_reorder_quantize_x`` (model/qLlamaLayer.py:73-77) in two launches, no host sync:
-    returns (QX, SFX, scale) with ``scale = max|X|/2688`` a 0-dim fp32 device tensor and (QX, SFX) byte-identical to
-    ``reorder_quantize_x(X / scale, reorder_index, KE)``."""
-    _need(X, torch.bfloat16, "X", 2)
+def _quantize_dynamic(entry: str, who: str, X: torch.Tensor, KQ: int, reorder_index: torch.Tensor, KE: int, variant):
     _need(reorder_index, torch.int16, "reorder_index", 1)
-    M, KQ = X.shape
+    M = X.shape[0]
     KE = int(KE)
     K = KQ + KE
     if variant is None:
         variant = variant_for_kq(KQ)
     if KQ % 16 or KE % 16 or KE < 0 or KE > KQ or K % 64 or reorder_index.numel() != KQ:
-        raise RuntimeError(f"Value error in reorder_quantize_x_dynamic: KQ={KQ}, KE={KE} is not valid")
+        raise RuntimeError(f"Value error in {who}: KQ={KQ}, KE={KE} is not valid")
     dev = X.device
     state = _dyn_state.get(dev)
     if state is None:                      # 8 bytes, zero once; every call leaves it zero again
@@ -196,10 +192,30 @@ def reorder_quantize_x_dynamic(X: torch.Tensor, reorder_index: torch.Tensor, KE:
     SFX = torch.empty((sf_buffer_bytes(M, K),), dtype=torch.uint8, device=dev)
     scale = torch.empty((1,), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        st = _lib.lib().arcq_quantize_x_dyn(X.data_ptr(), reorder_index.data_ptr(), QX.data_ptr(), SFX.data_ptr(), scale.data_ptr(),
-                                            state.data_ptr(), M, KQ, KE, int(variant), _stream(X))
-    _lib.check(st, "reorder_quantize_x_dynamic")
+        st = getattr(_lib.lib(), entry)(X.data_ptr(), reorder_index.data_ptr(), QX.data_ptr(), SFX.data_ptr(), scale.data_ptr(),
+                                        state.data_ptr(), M, KQ, KE, int(variant), _stream(X))
+    _lib.check(st, who)
     return QX, SFX, scale.reshape(())
+
+
+def reorder_quantize_x_dynamic(X: torch.Tensor, reorder_index: torch.Tensor, KE: int, variant=None):
+    """Extension: ``NVFP4_reorder_quantize_x`` (model/qLlamaLayer.py:73-77) without a host sync, in ONE launch
+    for decode-sized inputs (<= 256 KB) and two otherwise: returns (QX, SFX, scale) with ``scale = max|X|/2688`` a 0-dim
+    fp32 device tensor and (QX, SFX) byte-identical to ``reorder_quantize_x(X / scale, reorder_index, KE)``."""
+    _need(X, torch.bfloat16, "X", 2)
+    return _quantize_dynamic("arcq_quantize_x_dyn", "reorder_quantize_x_dynamic", X, X.shape[1], reorder_index, KE, variant)
+
+
+def silu_mul_quantize_x_dynamic(GU: torch.Tensor, reorder_index: torch.Tensor, KE: int, variant=None):
+    """Extension: the MLP's ``act_fn(gate) * up`` (model/qLlamaLayer.py:417, SiLU) folded into the dynamic quantiser.
+    ``GU`` is [M, 2*KQ] bf16 = (gate | up), the output of a fused gate_up projection; returns what
+    ``reorder_quantize_x_dynamic(F.silu(GU[:, :KQ]) * GU[:, KQ:], ...)`` returns, byte for byte, in two launches instead
+    of four and without materialising the product."""
+    _need(GU, torch.bfloat16, "GU", 2)
+    if GU.shape[1] % 2:
+        raise RuntimeError("Value error in silu_mul_quantize_x_dynamic: GU must hold gate and up halves of equal width")
+    return _quantize_dynamic("arcq_silu_mul_quantize_x_dyn", "silu_mul_quantize_x_dynamic", GU, GU.shape[1] // 2, reorder_index, KE,
+                             variant)
 
 
 # --- KV-cache functions of the reference module (bindings.cpp:576-581): OUT OF SCOPE (SURVEY.md row 12).

@@ -20,6 +20,8 @@ int rmsnorm_quantize_x(const void* X, const void* Wn, float eps, const int16_t* 
 int absmax_scale(const void* X, int64_t n, float* scale_out, hipStream_t stream);
 int quantize_x_dyn(const void* X, const int16_t* idx, uint8_t* QX, uint8_t* SFX, float* scale_out, void* state, int64_t M,
                    int64_t KQ, int64_t KE, int variant, hipStream_t stream);
+int silu_mul_quantize_x_dyn(const void* GU, const int16_t* idx, uint8_t* QX, uint8_t* SFX, float* scale_out, void* state, int64_t M,
+                            int64_t KQ, int64_t KE, int variant, hipStream_t stream);
 
 // gemm_skinny.hip / gemm_tile.hip
 struct GemmArgs {

@@ -85,6 +85,33 @@ __device__ __forceinline__ GroupQ quantize_group(float (&v)[16]) {
   return g;
 }
 
+// act = silu(gate) * up on bf16 bits, rounded where torch's two elementwise kernels round (model/qLlamaLayer.py:
+// `self.act_fn(gate) * up`): silu in fp32 as x / (1 + exp(-x)) -> bf16 (ActivationSiluKernel), then the fp32 product
+// -> bf16 (MulFunctor).  expf / the division are the same ocml / IEEE operations torch's HIP build uses.
+__device__ __forceinline__ uint32_t silu_mul_bf16(uint32_t g_bits, uint32_t u_bits) {
+  const float g = bf16_bits_to_f32(g_bits);
+  const float s = g / (1.0f + expf(-g));
+  const float sb = bf16_bits_to_f32(f32_to_bf16_bits(s));
+  return f32_to_bf16_bits(sb * bf16_bits_to_f32(u_bits));
+}
+__device__ __forceinline__ uint4 silu_mul_chunk(const uint4 g, const uint4 u) {
+  const uint32_t gw[4] = {g.x, g.y, g.z, g.w}, uw[4] = {u.x, u.y, u.z, u.w};
+  uint32_t o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    o[j] = silu_mul_bf16(gw[j] & 0xffffu, uw[j] & 0xffffu) | (silu_mul_bf16(gw[j] >> 16, uw[j] >> 16) << 16);
+  return make_uint4(o[0], o[1], o[2], o[3]);
+}
+__device__ __forceinline__ uint32_t absmax_bits_chunk(const uint4 d, uint32_t m) {
+  const uint32_t w4[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    m = max(m, w4[j] & 0x7fffu);
+    m = max(m, (w4[j] >> 16) & 0x7fffu);
+  }
+  return m;
+}
+
 // Sum of squares of one row in the reference's association order (rmsnorm.cu:113-154), so that the
 // fp32 result is bit-identical to the oracle's: virtual thread v in [0, KQ/16) owns the 16-byte
 // chunks v and KQ/16 + v, accumulates their 16 squares sequentially, then a fixed tree.
@@ -105,13 +132,20 @@ __device__ __forceinline__ float rms_sumsq_tree(float* s, int bdx) {
   return s[0];
 }
 
-// `dyn` (kModeX only, may be NULL): {amax bits, ticket} of the per-tensor dynamic scale (arcq_quantize_x_dyn).  When
-// set, every element is first divided by scale = amax * (1/2688) and rounded to bf16 -- exactly what torch's GPU
-// `x / scale` with a 0-dim fp32 scale computes (model/qLlamaLayer.py:74-76) -- so the separate abs/max/div passes vanish.
+// Per-tensor dynamic scale (kModeX only, arcq_quantize_x_dyn / arcq_silu_mul_quantize_x_dyn), selected by dyn_mode:
+//   kDynState: `dyn` = {amax bits, ticket} filled by a preceding abs-max kernel;
+//   kDynLocal: every workgroup computes max|X| of the WHOLE (small) tensor itself -- decode-sized inputs then need a
+//              single launch (a launch costs ~4.6 us in a replayed graph, re-reading <= 256 KB from L2 well under 1).
+// Every element is first divided by scale = amax * (1/2688) and rounded to bf16 -- exactly what torch's GPU `x / scale`
+// with a 0-dim fp32 scale computes (model/qLlamaLayer.py:74-76) -- so the separate abs/max/div passes vanish.
+// `Xup` (may be NULL): the row is silu(X) * Xup computed on the fly (both with row stride ldx).
+enum : int { kDynNone = 0, kDynState = 1, kDynLocal = 2 };
+
 template <int kVariant, int kMode>
 __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
-    const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wn, float eps, const int16_t* __restrict__ idx,
-    uint8_t* __restrict__ Q, uint8_t* __restrict__ SF, int rows, int KQ, int KE, unsigned int* dyn, float* scale_out) {
+    const uint16_t* __restrict__ X, const uint16_t* __restrict__ Xup, int64_t ldx, const uint16_t* __restrict__ Wn, float eps,
+    const int16_t* __restrict__ idx, uint8_t* __restrict__ Q, uint8_t* __restrict__ SF, int rows, int KQ, int KE, int dyn_mode,
+    unsigned int* dyn, float* scale_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t* row_lds = reinterpret_cast<uint16_t*>(smem);
   float* red = reinterpret_cast<float*>(smem + (size_t)KQ * 2);   // kModeRms only
@@ -128,8 +162,22 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
   const int g_begin = (int)blockIdx.y * g_per;
   const int g_end = min(G, g_begin + g_per);
   float dyn_scale = 1.0f;
-  if (kMode == kModeX && dyn) {
-    dyn_scale = bf16_bits_to_f32(*reinterpret_cast<volatile unsigned int*>(dyn)) * (1.0f / (448.0f * 6.0f));
+  if (kMode == kModeX && dyn_mode != kDynNone) {
+    unsigned int amax_bits;
+    if (dyn_mode == kDynLocal) {
+      __shared__ unsigned int wave_max[kQuantThreads / 64];
+      uint32_t m = 0;
+      for (int r = 0; r < rows; ++r)
+        for (int c = tid; c < chunks; c += kQuantThreads) m = absmax_bits_chunk(*reinterpret_cast<const uint4*>(X + (size_t)r * ldx + (size_t)c * 8), m);
+#pragma unroll
+      for (int sh = 32; sh > 0; sh >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, sh, 64));
+      if ((tid & 63) == 0) wave_max[tid >> 6] = m;
+      __syncthreads();
+      amax_bits = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+    } else {
+      amax_bits = *reinterpret_cast<volatile unsigned int*>(dyn);
+    }
+    dyn_scale = bf16_bits_to_f32(amax_bits) * (1.0f / (448.0f * 6.0f));
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) scale_out[0] = dyn_scale;      // the caller's fp32 per-tensor scale
     // torch on the GPU divides a bf16 tensor by a 0-dim fp32 tensor in the COMMON dtype bf16: the scale operand is
     // rounded to bf16 at load (BinaryFunctor<BFloat16, BFloat16, BFloat16, DivFunctor>), the quotient is formed in fp32
@@ -137,7 +185,7 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
   }
 
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
-    const uint16_t* xrow = X + (size_t)row * KQ;
+    const uint16_t* xrow = X + (size_t)row * ldx;
     float rstd = 1.0f;
     if (kMode == kModeRms) {
       for (int v = tid; v < bdx; v += kQuantThreads) {
@@ -161,8 +209,15 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
       float var = sum / (float)KQ + eps;                       // rmsnorm.cu:157
       rstd = (float)(1.0 / sqrt((double)var));                 // oracle assumption A4
     } else {
-      for (int c = tid; c < chunks; c += kQuantThreads)
-        *reinterpret_cast<uint4*>(row_lds + (size_t)c * 8) = *reinterpret_cast<const uint4*>(xrow + (size_t)c * 8);
+      if (kMode == kModeX && Xup) {
+        const uint16_t* urow = Xup + (size_t)row * ldx;
+        for (int c = tid; c < chunks; c += kQuantThreads)
+          *reinterpret_cast<uint4*>(row_lds + (size_t)c * 8) =
+              silu_mul_chunk(*reinterpret_cast<const uint4*>(xrow + (size_t)c * 8), *reinterpret_cast<const uint4*>(urow + (size_t)c * 8));
+      } else {
+        for (int c = tid; c < chunks; c += kQuantThreads)
+          *reinterpret_cast<uint4*>(row_lds + (size_t)c * 8) = *reinterpret_cast<const uint4*>(xrow + (size_t)c * 8);
+      }
       __syncthreads();
     }
 
@@ -177,7 +232,7 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
       for (int j = 0; j < 8; ++j) {
         const uint32_t ia = iw[j] & 0xffffu, ib = iw[j] >> 16;
         float a = bf16_bits_to_f32(row_lds[ia]), b = bf16_bits_to_f32(row_lds[ib]);
-        if (kMode == kModeX && dyn) {                           // torch: bf16(float(x) / scale)
+        if (kMode == kModeX && dyn_mode != kDynNone) {          // torch: bf16(float(x) / scale)
           a = bf16_bits_to_f32(f32_to_bf16_bits(a / dyn_scale));
           b = bf16_bits_to_f32(f32_to_bf16_bits(b / dyn_scale));
         }
@@ -228,7 +283,7 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
     }
     __syncthreads();   // row_lds is rewritten by the next row
   }
-  if (kMode == kModeX && dyn && tid == 0) {
+  if (kMode == kModeX && dyn_mode == kDynState && tid == 0) {
     // leave the state zeroed for the next call: the last workgroup to finish has seen every other one read it
     __threadfence();
     if (atomicAdd(dyn + 1, 1u) == gridDim.x * gridDim.y - 1) {
@@ -243,17 +298,24 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
 __global__ __launch_bounds__(256) void absmax_bits_kernel(const uint16_t* __restrict__ X, int64_t n8, int64_t n,
                                                            unsigned int* __restrict__ slot) {
   uint32_t m = 0;
-  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n8; c += (int64_t)gridDim.x * blockDim.x) {
-    uint4 d = *reinterpret_cast<const uint4*>(X + c * 8);
-    const uint32_t w4[4] = {d.x, d.y, d.z, d.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      m = max(m, w4[j] & 0x7fffu);
-      m = max(m, (w4[j] >> 16) & 0x7fffu);
-    }
-  }
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n8; c += (int64_t)gridDim.x * blockDim.x)
+    m = absmax_bits_chunk(*reinterpret_cast<const uint4*>(X + c * 8), m);
   if (blockIdx.x == 0)
     for (int64_t i = n8 * 8 + threadIdx.x; i < n; i += blockDim.x) m = max(m, (uint32_t)X[i] & 0x7fffu);
+#pragma unroll
+  for (int sh = 32; sh > 0; sh >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, sh, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(slot, m);
+}
+
+// max |silu(G) * U| over a [rows, KQ] view of two strided operands (KQ % 8 == 0), same bit-ordering trick
+__global__ __launch_bounds__(256) void silu_mul_absmax_kernel(const uint16_t* __restrict__ G, const uint16_t* __restrict__ U, int64_t ldx,
+                                                               int rows, int chunks, unsigned int* __restrict__ slot) {
+  uint32_t m = 0;
+  const int64_t total = (int64_t)rows * chunks;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / chunks, c = i - r * chunks;
+    m = absmax_bits_chunk(silu_mul_chunk(*reinterpret_cast<const uint4*>(G + r * ldx + c * 8), *reinterpret_cast<const uint4*>(U + r * ldx + c * 8)), m);
+  }
 #pragma unroll
   for (int sh = 32; sh > 0; sh >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, sh, 64));
   if ((threadIdx.x & 63) == 0) atomicMax(slot, m);
@@ -274,7 +336,8 @@ constexpr int kMaxQuantBlocks = 2048;   // 256 CUs x 8 resident workgroups, rows
 template <int kMode>
 static int launch_quantize(const void* X, const void* Wn, float eps, const int16_t* idx, uint8_t* Q, uint8_t* SF,
                            int64_t rows, int64_t KQ, int64_t KE, int variant, hipStream_t stream, const char* who,
-                           unsigned int* dyn = nullptr, float* scale_out = nullptr) {
+                           int dyn_mode = kDynNone, unsigned int* dyn = nullptr, float* scale_out = nullptr, const void* Xup = nullptr,
+                           int64_t ldx = 0) {
   if (rows < 0 || KQ <= 0 || (KQ % 16) || (KE % 16) || KE < 0 || KE > KQ || ((KQ + KE) % 64))
     return fail(ARCQ_ERR_SHAPE, "%s: need KQ%%16==0, KE%%16==0, 0<=KE<=KQ, (KQ+KE)%%64==0 (rows=%lld KQ=%lld KE=%lld)", who,
                 (long long)rows, (long long)KQ, (long long)KE);
@@ -301,8 +364,8 @@ static int launch_quantize(const void* X, const void* Wn, float eps, const int16
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "%s: cannot reserve %zu B of LDS: %s", who, lds, hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(kern, dim3(grid, gsplit), dim3(kQuantThreads), lds, stream, (const uint16_t*)X, (const uint16_t*)Wn, eps, idx,
-                       Q, SF, (int)rows, (int)KQ, (int)KE, dyn, scale_out);
+    hipLaunchKernelGGL(kern, dim3(grid, gsplit), dim3(kQuantThreads), lds, stream, (const uint16_t*)X, (const uint16_t*)Xup,
+                       ldx ? ldx : KQ, (const uint16_t*)Wn, eps, idx, Q, SF, (int)rows, (int)KQ, (int)KE, dyn_mode, dyn, scale_out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "%s: launch failed: %s", who, hipGetErrorString(e));
     return ARCQ_OK;
@@ -324,6 +387,9 @@ int rmsnorm_quantize_x(const void* X, const void* Wn, float eps, const int16_t* 
   return launch_quantize<kModeRms>(X, Wn, eps, idx, QX, SFX, M, KQ, KE, variant, stream, "arcq_rmsnorm_quantize_x");
 }
 
+// Largest input (bytes) for which every workgroup recomputes max|X| itself instead of a separate abs-max launch
+constexpr int64_t kDynLocalMaxBytes = 256 * 1024;
+
 int quantize_x_dyn(const void* X, const int16_t* idx, uint8_t* QX, uint8_t* SFX, float* scale_out, void* state, int64_t M,
                    int64_t KQ, int64_t KE, int variant, hipStream_t stream) {
   if (!scale_out || !state) return fail(ARCQ_ERR_NULL, "arcq_quantize_x_dyn: NULL scale_out / state");
@@ -333,13 +399,34 @@ int quantize_x_dyn(const void* X, const int16_t* idx, uint8_t* QX, uint8_t* SFX,
   if (rc != ARCQ_OK || M <= 0) return rc;
   if (!X || !idx || !QX || !SFX) return fail(ARCQ_ERR_NULL, "arcq_quantize_x_dyn: NULL pointer");
   if ((reinterpret_cast<uintptr_t>(X) & 15) != 0) return fail(ARCQ_ERR_SHAPE, "arcq_quantize_x_dyn: X must be 16-byte aligned");
-  if (KQ <= 0 || (KQ % 16)) return fail(ARCQ_ERR_SHAPE, "arcq_quantize_x_dyn: KQ %% 16 != 0");
   unsigned int* st = reinterpret_cast<unsigned int*>(state);
   const int64_t n = M * KQ, n8 = n / 8;
+  if (n * 2 <= kDynLocalMaxBytes)     // decode-sized: one launch, `state` untouched
+    return launch_quantize<kModeX>(X, nullptr, 0.f, idx, QX, SFX, M, KQ, KE, variant, stream, "arcq_quantize_x_dyn", kDynLocal, nullptr, scale_out);
   int64_t want = (n8 + 255) / 256;
   const int grid = (int)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
   hipLaunchKernelGGL(absmax_bits_kernel, dim3(grid), dim3(256), 0, stream, (const uint16_t*)X, n8, n, st);
-  return launch_quantize<kModeX>(X, nullptr, 0.f, idx, QX, SFX, M, KQ, KE, variant, stream, "arcq_quantize_x_dyn", st, scale_out);
+  return launch_quantize<kModeX>(X, nullptr, 0.f, idx, QX, SFX, M, KQ, KE, variant, stream, "arcq_quantize_x_dyn", kDynState, st, scale_out);
+}
+
+// GU = [M, 2*KQ] bf16 (gate | up, the fused gate_up projection's output): quantise silu(gate) * up with its
+// per-tensor dynamic scale.  Two launches (abs-max of the product, quantise), the product is never materialised.
+int silu_mul_quantize_x_dyn(const void* GU, const int16_t* idx, uint8_t* QX, uint8_t* SFX, float* scale_out, void* state, int64_t M,
+                            int64_t KQ, int64_t KE, int variant, hipStream_t stream) {
+  const char* who = "arcq_silu_mul_quantize_x_dyn";
+  if (!scale_out || !state) return fail(ARCQ_ERR_NULL, "%s: NULL scale_out / state", who);
+  const int rc = launch_quantize<kModeX>(GU, nullptr, 0.f, idx, QX, SFX, 0, KQ, KE, variant, stream, who);
+  if (rc != ARCQ_OK || M <= 0) return rc;
+  if (!GU || !idx || !QX || !SFX) return fail(ARCQ_ERR_NULL, "%s: NULL pointer", who);
+  if ((reinterpret_cast<uintptr_t>(GU) & 15) != 0) return fail(ARCQ_ERR_SHAPE, "%s: GU must be 16-byte aligned", who);
+  unsigned int* st = reinterpret_cast<unsigned int*>(state);
+  const uint16_t* G = reinterpret_cast<const uint16_t*>(GU);
+  const uint16_t* U = G + KQ;
+  const int64_t chunks = KQ / 8, total = M * chunks;
+  int64_t want = (total + 255) / 256;
+  const int grid = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+  hipLaunchKernelGGL(silu_mul_absmax_kernel, dim3(grid), dim3(256), 0, stream, G, U, 2 * KQ, (int)M, (int)chunks, st);
+  return launch_quantize<kModeX>(G, nullptr, 0.f, idx, QX, SFX, M, KQ, KE, variant, stream, who, kDynState, st, scale_out, U, 2 * KQ);
 }
 
 int absmax_scale(const void* X, int64_t n, float* scale_out, hipStream_t stream) {

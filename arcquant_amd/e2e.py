@@ -140,8 +140,7 @@ class DecoderModel:
             A, SFA = agemm.rmsnorm_quantize_x(hcur, L["ln2"], cfg.eps, self.idx_h, cfg.select_num)
             if self.fused:
                 gu = agemm.matmul(A, L["gateup"].W, SFA, L["gateup"].SFW, L["gateup"].scale)
-                act = F.silu(gu[:, :it]) * gu[:, it:]
-                qa, sfa, sa = agemm.reorder_quantize_x_dynamic(act, self.idx_i, cfg.select_num)
+                qa, sfa, sa = agemm.silu_mul_quantize_x_dynamic(gu, self.idx_i, cfg.select_num)   # act_fn(gate) * up, fused
                 hcur = agemm.matmul(qa, L["down"].W, sfa, L["down"].SFW, sa, scale_host=L["down"].scale_f, residual=hcur)
             else:
                 gate = agemm.matmul(A, L["gate"].W, SFA, L["gate"].SFW, L["gate"].scale)

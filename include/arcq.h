@@ -121,6 +121,13 @@ int arcq_absmax_scale(const void *X, int64_t n, float *scale_out, void *stream);
 int arcq_quantize_x_dyn(const void *X, const int16_t *reorder_index, uint8_t *QX, uint8_t *SFX, float *scale_out,
                         void *state, int64_t M, int64_t KQ, int64_t KE, int variant, void *stream);
 
+/* Extension: the MLP's `act_fn(gate) * up` (model/qLlamaLayer.py:417, SiLU) folded into the dynamic quantiser.
+ * GU = [M, 2*KQ] bf16, gate in columns [0, KQ) and up in [KQ, 2*KQ) (the output of a fused gate_up projection);
+ * equals arcq_quantize_x_dyn on the bf16 tensor torch computes as silu(gate) * up, which is never materialised.
+ * `state` as above. */
+int arcq_silu_mul_quantize_x_dyn(const void *GU, const int16_t *reorder_index, uint8_t *QX, uint8_t *SFX, float *scale_out,
+                                 void *state, int64_t M, int64_t KQ, int64_t KE, int variant, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

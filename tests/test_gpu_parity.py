@@ -376,6 +376,40 @@ def test_dynamic_quantizer_equals_torch_prescale_pipeline():
             x = -x * 0.5       # second round with a different maximum
 
 
+def _used_sf_mask(M, K, numel):
+    used = torch.zeros(numel, dtype=torch.bool)
+    r = torch.arange(M).unsqueeze(1)
+    p = torch.arange(K // 16).unsqueeze(0)
+    off = ((r // 128) * (K // 64) + p // 4) * 512 + (r % 32) * 16 + ((r // 32) % 4) * 4 + p % 4
+    used[off.reshape(-1)] = True
+    return used
+
+
+def test_silu_mul_quantizer_equals_torch_pipeline():
+    """silu_mul_quantize_x_dynamic(gate|up) == the reference MLP's torch steps (model/qLlamaLayer.py:417
+    `act_fn(gate) * up`, then :73-77) byte for byte: the bf16 roundings of torch's silu and mul kernels and its
+    exp / divide are reproduced inside the quantiser."""
+    import torch.nn.functional as F
+    ag = _agemm()
+    for (M, KQ, KE) in [(4, 18944, 64), (1, 3584, 64), (8, 512, 64), (300, 2048, 128)]:
+        g = torch.Generator().manual_seed(7 * M + KQ)
+        gu = (torch.randn(M, 2 * KQ, generator=g) * 3).to(torch.bfloat16)
+        gu[0, :4] = torch.tensor([0.0, -0.0, 60.0, -60.0]).to(torch.bfloat16)      # exp under/overflow ends
+        gu[0, 4:8] = torch.tensor([-100.0, 100.0, 1e-3, -1e-3]).to(torch.bfloat16)
+        gu = gu.to(DEV)
+        idx = random_perm(KQ, 43).to(DEV)
+        act = F.silu(gu[:, :KQ]) * gu[:, KQ:]
+        want_q, want_sf, want_scale = ag.reorder_quantize_x_dynamic(act.contiguous(), idx, KE)
+        for _ in range(2):
+            got_q, got_sf, got_scale = ag.silu_mul_quantize_x_dynamic(gu, idx, KE)
+            assert got_scale.item() == want_scale.item()
+            assert torch.equal(got_q, want_q)
+            used = _used_sf_mask(M, KQ + KE, got_sf.numel())
+            assert torch.equal(got_sf.cpu()[used], want_sf.cpu()[used])
+    with pytest.raises(RuntimeError):
+        ag.silu_mul_quantize_x_dynamic(gu[:, :-1].contiguous(), idx, 64)
+
+
 def test_gemm_residual_epilogue_matches_torch_add():
     ag = _agemm()
     for M, KQ in ((4, 512), (130, 512), (40, 1984), (90, 1984)):          # the last two finish through split-K
