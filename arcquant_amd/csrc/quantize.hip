@@ -209,7 +209,10 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
       float var = sum / (float)KQ + eps;                       // rmsnorm.cu:157
       rstd = (float)(1.0 / sqrt((double)var));                 // oracle assumption A4
     } else {
-      if (kMode == kModeX && Xup) {
+      if (kMode == kModeX && Xup && gridDim.y > 1) {
+        // decode-sized silu*up: a staged row would be recomputed (one exp per element) by each of the gridDim.y
+        // workgroups that share it; gather straight from global instead, every element is then computed once
+      } else if (kMode == kModeX && Xup) {
         const uint16_t* urow = Xup + (size_t)row * ldx;
         for (int c = tid; c < chunks; c += kQuantThreads)
           *reinterpret_cast<uint4*>(row_lds + (size_t)c * 8) =
@@ -231,7 +234,15 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const uint32_t ia = iw[j] & 0xffffu, ib = iw[j] >> 16;
-        float a = bf16_bits_to_f32(row_lds[ia]), b = bf16_bits_to_f32(row_lds[ib]);
+        float a, b;
+        if (kMode == kModeX && Xup && gridDim.y > 1) {
+          const uint16_t* urow = Xup + (size_t)row * ldx;
+          a = bf16_bits_to_f32(silu_mul_bf16(xrow[ia], urow[ia]));
+          b = bf16_bits_to_f32(silu_mul_bf16(xrow[ib], urow[ib]));
+        } else {
+          a = bf16_bits_to_f32(row_lds[ia]);
+          b = bf16_bits_to_f32(row_lds[ib]);
+        }
         if (kMode == kModeX && dyn_mode != kDynNone) {          // torch: bf16(float(x) / scale)
           a = bf16_bits_to_f32(f32_to_bf16_bits(a / dyn_scale));
           b = bf16_bits_to_f32(f32_to_bf16_bits(b / dyn_scale));
