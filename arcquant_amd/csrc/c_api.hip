@@ -85,12 +85,14 @@ int arcq_absmax_scale(const void* X, int64_t n, float* scale_out, void* stream) 
 static const int64_t kSkinnyMaxM = 16;
 
 // M <= 16: the 32-row-tile kernel needs enough tiles to occupy the chip without split-K (its tiles are twice as
-// tall); below that the 16-row-tile kernel wins.  ARCQ_DECODE=1|2 forces the first / second generation (tuning).
+// tall); below that the 16-row-tile kernel wins.  Measured crossover (tools/decode_bench.py, M=4, K=4160, us):
+// N=4096 7.3 vs 9.3, N=5120 9.2 vs 8.5, N=8192 10.2 vs 9.5, N=14336 16.0 vs 14.6, N=37888 28.7 vs 23.9.
+// ARCQ_DECODE=1|2 forces the 16-row / 32-row kernel (tuning).
 static bool use_decode_v2(int64_t N) {
   static const int forced = getenv("ARCQ_DECODE") ? atoi(getenv("ARCQ_DECODE")) : 0;
   if (forced == 1) return false;
   if (forced == 2) return true;
-  return ((N + 127) / 128) * 4 >= 256;
+  return ((N + 127) / 128) * 4 >= 160;
 }
 
 int64_t arcq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {

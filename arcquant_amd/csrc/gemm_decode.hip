@@ -26,6 +26,7 @@
 //   * packed bytes are transposed into the MFMA operand layout through a double-buffered LDS image
 //     (padded rows: conflict-free), one barrier per item; cross-wave reduction through LDS per tile;
 //     fused epilogue; split-K over slabs (second pass) only when the tiles alone cannot fill the chip.
+// Used from N = 5120 up (c_api.hip); below that a workgroup lives for 2-5 items and gemm_skinny.hip is faster.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>

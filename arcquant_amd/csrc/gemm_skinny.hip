@@ -1,4 +1,4 @@
-// ARC-NVFP4 GEMM for decode shapes (M <= 16) with FEW weight tiles (N < 8192): the latency-bound member of the
+// ARC-NVFP4 GEMM for decode shapes (M <= 16) with FEW weight tiles (N < 5120): the latency-bound member of the
 // decode pair (gemm_decode.hip is the throughput-bound one; c_api.hip picks).
 //
 // Replaces the CUTLASS 128x128x128 block-scaled GEMM of the reference (kernels/src/nvfp4.cu:35-132)
@@ -15,7 +15,7 @@
 //     Three items are requested before the first is used; the item loop is ROLLED (ring rotated by moves) to
 //     keep the code small -- the rotation makes hipcc wait for the youngest load, which costs steady-state
 //     depth this kernel does not live long enough to use (the unrolled, exactly-counted ring of gemm_decode.hip
-//     measured 5.9 -> 6.7 us here on N=K=3584 and wins only from N = 8192 up)
+//     measured 5.9 -> 6.7 us here on N=K=3584 and wins only from N = 5120 up)
 //   * the packed bytes are transposed into the MFMA operand layout through a small double-buffered LDS
 //     image (padded rows: conflict-free), one barrier per item
 //   * a tile's 16 rows are {32j + 4t + i} of a 128-row super-tile: their scale bytes then fill whole

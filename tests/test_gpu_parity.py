@@ -164,6 +164,10 @@ GEMM_CASES = [
     (100, 384, 2048, 128, O.G32),     # 128x128 tile, split-K
     (40, 130, 2048, 0, O.G16),        # N % 4 != 0: the split is refused, one pass over K
     (520, 256, 1024, 64, O.G16),      # several M tiles x split-K
+    (4, 5120, 1088, 64, O.G16),       # 32-row-tile decode kernel (N >= 5120), partial tail slab
+    (9, 5250, 512, 64, O.G16),        # ... ragged N, N % 4 != 0, two activation dwords per thread
+    (16, 5120, 2048, 128, O.G32),     # ... four activation dwords per thread, three slabs
+    (1, 6144, 256, 0, O.G16),         # ... a single short slab
 ]
 
 
