@@ -185,9 +185,10 @@ def _quantize_dynamic(entry: str, who: str, X: torch.Tensor, KQ: int, reorder_in
     if KQ % 16 or KE % 16 or KE < 0 or KE > KQ or K % 64 or reorder_index.numel() != KQ:
         raise RuntimeError(f"Value error in {who}: KQ={KQ}, KE={KE} is not valid")
     dev = X.device
-    state = _dyn_state.get(dev)
-    if state is None:                      # 8 bytes, zero once; every call leaves it zero again
-        state = _dyn_state[dev] = torch.zeros(2, dtype=torch.int32, device=dev)
+    key = (dev, _stream(X))                # scratch of the abs-max pass: one per device and stream (include/arcq.h)
+    state = _dyn_state.get(key)
+    if state is None:
+        state = _dyn_state[key] = torch.empty(256, dtype=torch.int32, device=dev)
     QX = torch.empty((M, K // 2), dtype=torch.uint8, device=dev)
     SFX = torch.empty((sf_buffer_bytes(M, K),), dtype=torch.uint8, device=dev)
     scale = torch.empty((1,), dtype=torch.float32, device=dev)

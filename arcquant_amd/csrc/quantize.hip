@@ -132,23 +132,28 @@ __device__ __forceinline__ float rms_sumsq_tree(float* s, int bdx) {
   return s[0];
 }
 
-// Per-tensor dynamic scale (kModeX only, arcq_quantize_x_dyn / arcq_silu_mul_quantize_x_dyn), selected by dyn_mode:
-//   kDynState: `dyn` = {amax bits, ticket} filled by a preceding abs-max kernel;
+// Per-tensor dynamic scale (kModeX only, arcq_quantize_x_dyn / arcq_silu_mul_quantize_x_dyn), selected by kDyn:
+//   kDynState: `dyn` = one abs-max word per workgroup of a preceding abs-max kernel (`nslots` of them, plain stores:
+//              4096 same-address atomics, or a completion ticket taken by 2048 workgroups, serialise on the fabric and
+//              cost 50-100 us -- measured -- where the data pass itself takes 15);
 //   kDynLocal: every workgroup computes max|X| of the WHOLE (small) tensor itself -- decode-sized inputs then need a
 //              single launch (a launch costs ~4.6 us in a replayed graph, re-reading <= 256 KB from L2 well under 1).
 // Every element is first divided by scale = amax * (1/2688) and rounded to bf16 -- exactly what torch's GPU `x / scale`
 // with a 0-dim fp32 scale computes (model/qLlamaLayer.py:74-76) -- so the separate abs/max/div passes vanish.
-// `Xup` (may be NULL): the row is silu(X) * Xup computed on the fly (both with row stride ldx).
+// kSilu: the row is silu(X) * Xup computed on the fly (both with row stride ldx).
+// kDyn / kSilu are template parameters: as run-time branches inside the 16-element gather they cost the static
+// quantiser 18 % (15.7 -> 18.5 us at 4096^2) and the dynamic one most of its time.
 enum : int { kDynNone = 0, kDynState = 1, kDynLocal = 2 };
 
-template <int kVariant, int kMode>
+template <int kVariant, int kMode, int kDyn, bool kSilu>
 __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
     const uint16_t* __restrict__ X, const uint16_t* __restrict__ Xup, int64_t ldx, const uint16_t* __restrict__ Wn, float eps,
-    const int16_t* __restrict__ idx, uint8_t* __restrict__ Q, uint8_t* __restrict__ SF, int rows, int KQ, int KE, int dyn_mode,
-    unsigned int* dyn, float* scale_out) {
+    const int16_t* __restrict__ idx, uint8_t* __restrict__ Q, uint8_t* __restrict__ SF, int rows, int KQ, int KE,
+    const unsigned int* __restrict__ dyn, int nslots, float* scale_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t* row_lds = reinterpret_cast<uint16_t*>(smem);
-  float* red = reinterpret_cast<float*>(smem + (size_t)KQ * 2);   // kModeRms only
+  float* red = reinterpret_cast<float*>(smem + (size_t)KQ * 2);   // kModeRms only: 512 floats of reduction scratch ...
+  uint16_t* wn_lds = reinterpret_cast<uint16_t*>(smem + (size_t)KQ * 2 + 512 * sizeof(float));   // ... and the norm weights
 
   const int tid = threadIdx.x;
   const int K = KQ + KE;
@@ -162,28 +167,50 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
   const int g_begin = (int)blockIdx.y * g_per;
   const int g_end = min(G, g_begin + g_per);
   float dyn_scale = 1.0f;
-  if (kMode == kModeX && dyn_mode != kDynNone) {
-    unsigned int amax_bits;
-    if (dyn_mode == kDynLocal) {
-      __shared__ unsigned int wave_max[kQuantThreads / 64];
-      uint32_t m = 0;
+  if (kDyn != kDynNone) {
+    __shared__ unsigned int wave_max[kQuantThreads / 64];
+    uint32_t m = 0;
+    if (kDyn == kDynLocal) {
       for (int r = 0; r < rows; ++r)
         for (int c = tid; c < chunks; c += kQuantThreads) m = absmax_bits_chunk(*reinterpret_cast<const uint4*>(X + (size_t)r * ldx + (size_t)c * 8), m);
-#pragma unroll
-      for (int sh = 32; sh > 0; sh >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, sh, 64));
-      if ((tid & 63) == 0) wave_max[tid >> 6] = m;
-      __syncthreads();
-      amax_bits = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
     } else {
-      amax_bits = *reinterpret_cast<volatile unsigned int*>(dyn);
+      for (int i = tid; i < nslots; i += kQuantThreads) m = max(m, dyn[i]);
     }
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, sh, 64));
+    if ((tid & 63) == 0) wave_max[tid >> 6] = m;
+    __syncthreads();
+    const unsigned int amax_bits = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
     dyn_scale = bf16_bits_to_f32(amax_bits) * (1.0f / (448.0f * 6.0f));
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) scale_out[0] = dyn_scale;      // the caller's fp32 per-tensor scale
     // torch on the GPU divides a bf16 tensor by a 0-dim fp32 tensor in the COMMON dtype bf16: the scale operand is
     // rounded to bf16 at load (BinaryFunctor<BFloat16, BFloat16, BFloat16, DivFunctor>), the quotient is formed in fp32
     dyn_scale = bf16_bits_to_f32(f32_to_bf16_bits(dyn_scale));
   }
+  // x / scale without ten instructions of IEEE division per element: q = x * r corrected by two FMAs (Markstein) and
+  // the sign of x restored (-0 / s = -0).  With r = RN(1 / scale) this IS the correctly rounded quotient; checked
+  // EXHAUSTIVELY on MI355X for every finite bf16 x with |x| <= 4096 scale and every bf16 scale in 2^-100 .. 2^100
+  // (tools/probe_div.hip: 0 mismatches after the bf16 rounding; |x / scale| <= 2688 holds by construction).  Scales
+  // outside that range take the IEEE division.
+  const float dyn_rcp = 1.0f / dyn_scale;
+  const bool dyn_fast = kDyn != kDynNone && dyn_scale >= 0x1p-100f && dyn_scale <= 0x1p100f;
+  auto div_scale = [&](float x) -> float {
+    if (__builtin_expect(dyn_fast, 1)) {
+      float q = x * dyn_rcp;
+      const float e = __builtin_fmaf(-q, dyn_scale, x);
+      q = __builtin_fmaf(e, dyn_rcp, q);
+      return __builtin_copysignf(q, x);
+    }
+    return x / dyn_scale;
+  };
 
+  if (kMode == kModeRms) {
+    // the gather reads the norm weight of every channel: 16 scattered 2-byte global loads per group cost 2.6x
+    // the whole static quantiser (41 vs 16 us at 4096^2), one LDS copy per workgroup does not
+    for (int c = threadIdx.x; c < chunks; c += kQuantThreads)
+      *reinterpret_cast<uint4*>(wn_lds + (size_t)c * 8) = *reinterpret_cast<const uint4*>(Wn + (size_t)c * 8);
+    // visible after the barriers of the first row's reduction
+  }
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     const uint16_t* xrow = X + (size_t)row * ldx;
     float rstd = 1.0f;
@@ -209,10 +236,10 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
       float var = sum / (float)KQ + eps;                       // rmsnorm.cu:157
       rstd = (float)(1.0 / sqrt((double)var));                 // oracle assumption A4
     } else {
-      if (kMode == kModeX && Xup && gridDim.y > 1) {
+      if (kSilu && gridDim.y > 1) {
         // decode-sized silu*up: a staged row would be recomputed (one exp per element) by each of the gridDim.y
         // workgroups that share it; gather straight from global instead, every element is then computed once
-      } else if (kMode == kModeX && Xup) {
+      } else if (kSilu) {
         const uint16_t* urow = Xup + (size_t)row * ldx;
         for (int c = tid; c < chunks; c += kQuantThreads)
           *reinterpret_cast<uint4*>(row_lds + (size_t)c * 8) =
@@ -235,7 +262,7 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
       for (int j = 0; j < 8; ++j) {
         const uint32_t ia = iw[j] & 0xffffu, ib = iw[j] >> 16;
         float a, b;
-        if (kMode == kModeX && Xup && gridDim.y > 1) {
+        if (kSilu && gridDim.y > 1) {
           const uint16_t* urow = Xup + (size_t)row * ldx;
           a = bf16_bits_to_f32(silu_mul_bf16(xrow[ia], urow[ia]));
           b = bf16_bits_to_f32(silu_mul_bf16(xrow[ib], urow[ib]));
@@ -243,13 +270,13 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
           a = bf16_bits_to_f32(row_lds[ia]);
           b = bf16_bits_to_f32(row_lds[ib]);
         }
-        if (kMode == kModeX && dyn_mode != kDynNone) {          // torch: bf16(float(x) / scale)
-          a = bf16_bits_to_f32(f32_to_bf16_bits(a / dyn_scale));
-          b = bf16_bits_to_f32(f32_to_bf16_bits(b / dyn_scale));
+        if (kDyn != kDynNone) {                                 // torch: bf16(float(x) / scale)
+          a = bf16_bits_to_f32(f32_to_bf16_bits(div_scale(a)));
+          b = bf16_bits_to_f32(f32_to_bf16_bits(div_scale(b)));
         }
         if (kMode == kModeRms) {                                // rmsnorm.cu:165-171
-          a = bf16_bits_to_f32(f32_to_bf16_bits(a * bf16_bits_to_f32(Wn[ia]) * rstd));
-          b = bf16_bits_to_f32(f32_to_bf16_bits(b * bf16_bits_to_f32(Wn[ib]) * rstd));
+          a = bf16_bits_to_f32(f32_to_bf16_bits(a * bf16_bits_to_f32(wn_lds[ia]) * rstd));
+          b = bf16_bits_to_f32(f32_to_bf16_bits(b * bf16_bits_to_f32(wn_lds[ib]) * rstd));
         }
         v[2 * j] = a;
         v[2 * j + 1] = b;
@@ -294,42 +321,54 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
     }
     __syncthreads();   // row_lds is rewritten by the next row
   }
-  if (kMode == kModeX && dyn_mode == kDynState && tid == 0) {
-    // leave the state zeroed for the next call: the last workgroup to finish has seen every other one read it
-    __threadfence();
-    if (atomicAdd(dyn + 1, 1u) == gridDim.x * gridDim.y - 1) {
-      dyn[0] = 0u;
-      dyn[1] = 0u;
-    }
-  }
 }
 
-// scale_out[0] = max|x| / 2688 (model/qLlamaLayer.py:73-77 without the host round trip).
-// |bf16| ordering == ordering of the low 15 bits, so an integer atomicMax is exact.
-__global__ __launch_bounds__(256) void absmax_bits_kernel(const uint16_t* __restrict__ X, int64_t n8, int64_t n,
-                                                           unsigned int* __restrict__ slot) {
+// max|x| helpers.  |bf16| ordering == ordering of the low 15 bits, so integer max is exact.
+constexpr int kAbsmaxThreads = 1024;     // one 16-wave workgroup per CU streams well and keeps the slot count small
+constexpr int kAbsmaxMaxBlocks = 256;    // == ARCQ_DYN_STATE_BYTES / 4
+
+// workgroup maximum of `m`; valid in thread 0
+__device__ __forceinline__ uint32_t block_max_bits(uint32_t m) {
+  __shared__ uint32_t wmax[kAbsmaxThreads / 64];
+#pragma unroll
+  for (int sh = 32; sh > 0; sh >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, sh, 64));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    m = threadIdx.x < (blockDim.x >> 6) ? wmax[threadIdx.x] : 0u;
+#pragma unroll
+    for (int sh = 8; sh > 0; sh >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, sh, 64));
+  }
+  return m;
+}
+
+// slots[blockIdx.x] = max |X| over this workgroup's share (kAtomic: atomicMax into slots[0] instead, <= 256 of them)
+template <bool kAtomic>
+__global__ __launch_bounds__(kAbsmaxThreads) void absmax_bits_kernel(const uint16_t* __restrict__ X, int64_t n8, int64_t n,
+                                                                      unsigned int* __restrict__ slots) {
   uint32_t m = 0;
   for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n8; c += (int64_t)gridDim.x * blockDim.x)
     m = absmax_bits_chunk(*reinterpret_cast<const uint4*>(X + c * 8), m);
   if (blockIdx.x == 0)
     for (int64_t i = n8 * 8 + threadIdx.x; i < n; i += blockDim.x) m = max(m, (uint32_t)X[i] & 0x7fffu);
-#pragma unroll
-  for (int sh = 32; sh > 0; sh >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, sh, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(slot, m);
+  m = block_max_bits(m);
+  if (threadIdx.x == 0) {
+    if (kAtomic) atomicMax(slots, m);
+    else slots[blockIdx.x] = m;
+  }
 }
 
-// max |silu(G) * U| over a [rows, KQ] view of two strided operands (KQ % 8 == 0), same bit-ordering trick
-__global__ __launch_bounds__(256) void silu_mul_absmax_kernel(const uint16_t* __restrict__ G, const uint16_t* __restrict__ U, int64_t ldx,
-                                                               int rows, int chunks, unsigned int* __restrict__ slot) {
+// slots[blockIdx.x] = max |silu(G) * U| over a [rows, KQ] view of two strided operands (KQ % 8 == 0)
+__global__ __launch_bounds__(kAbsmaxThreads) void silu_mul_absmax_kernel(const uint16_t* __restrict__ G, const uint16_t* __restrict__ U,
+                                                                          int64_t ldx, int rows, int chunks, unsigned int* __restrict__ slots) {
   uint32_t m = 0;
   const int64_t total = (int64_t)rows * chunks;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / chunks, c = i - r * chunks;
     m = absmax_bits_chunk(silu_mul_chunk(*reinterpret_cast<const uint4*>(G + r * ldx + c * 8), *reinterpret_cast<const uint4*>(U + r * ldx + c * 8)), m);
   }
-#pragma unroll
-  for (int sh = 32; sh > 0; sh >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, sh, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(slot, m);
+  m = block_max_bits(m);
+  if (threadIdx.x == 0) slots[blockIdx.x] = m;
 }
 
 __global__ void absmax_finish_kernel(unsigned int* slot, float* scale_out) {
@@ -344,10 +383,10 @@ __global__ void absmax_finish_kernel(unsigned int* slot, float* scale_out) {
 // ----------------------------------------------------------------------------------------------------
 constexpr int kMaxQuantBlocks = 2048;   // 256 CUs x 8 resident workgroups, rows are grid-strided beyond
 
-template <int kMode>
+template <int kMode, int kDyn = kDynNone, bool kSilu = false>
 static int launch_quantize(const void* X, const void* Wn, float eps, const int16_t* idx, uint8_t* Q, uint8_t* SF,
                            int64_t rows, int64_t KQ, int64_t KE, int variant, hipStream_t stream, const char* who,
-                           int dyn_mode = kDynNone, unsigned int* dyn = nullptr, float* scale_out = nullptr, const void* Xup = nullptr,
+                           const unsigned int* dyn = nullptr, int nslots = 0, float* scale_out = nullptr, const void* Xup = nullptr,
                            int64_t ldx = 0) {
   if (rows < 0 || KQ <= 0 || (KQ % 16) || (KE % 16) || KE < 0 || KE > KQ || ((KQ + KE) % 64))
     return fail(ARCQ_ERR_SHAPE, "%s: need KQ%%16==0, KE%%16==0, 0<=KE<=KQ, (KQ+KE)%%64==0 (rows=%lld KQ=%lld KE=%lld)", who,
@@ -365,7 +404,7 @@ static int launch_quantize(const void* X, const void* Wn, float eps, const int16
   if (!X || !idx || !Q || !SF || (kMode == kModeRms && !Wn)) return fail(ARCQ_ERR_NULL, "%s: NULL pointer", who);
   if (rows > INT32_MAX) return fail(ARCQ_ERR_UNSUPPORTED, "%s: too many rows", who);
 
-  size_t lds = (size_t)KQ * 2 + (kMode == kModeRms ? 512 * sizeof(float) : 0);
+  size_t lds = (size_t)KQ * 2 + (kMode == kModeRms ? 512 * sizeof(float) + (size_t)KQ * 2 : 0);
   const int grid = (int)(rows < kMaxQuantBlocks ? rows : kMaxQuantBlocks);
   // few rows (decode): also split each row over up to 16 workgroups of >= 32 groups so that the chip is not idle
   int gsplit = 1;
@@ -376,13 +415,13 @@ static int launch_quantize(const void* X, const void* Wn, float eps, const int16
       if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "%s: cannot reserve %zu B of LDS: %s", who, lds, hipGetErrorString(e));
     }
     hipLaunchKernelGGL(kern, dim3(grid, gsplit), dim3(kQuantThreads), lds, stream, (const uint16_t*)X, (const uint16_t*)Xup,
-                       ldx ? ldx : KQ, (const uint16_t*)Wn, eps, idx, Q, SF, (int)rows, (int)KQ, (int)KE, dyn_mode, dyn, scale_out);
+                       ldx ? ldx : KQ, (const uint16_t*)Wn, eps, idx, Q, SF, (int)rows, (int)KQ, (int)KE, dyn, nslots, scale_out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "%s: launch failed: %s", who, hipGetErrorString(e));
     return ARCQ_OK;
   };
-  if (variant == ARCQ_VARIANT_G16) return go(quantize_rows_kernel<ARCQ_VARIANT_G16, kMode>);
-  return go(quantize_rows_kernel<ARCQ_VARIANT_G32, kMode>);
+  if (variant == ARCQ_VARIANT_G16) return go(quantize_rows_kernel<ARCQ_VARIANT_G16, kMode, kDyn, kSilu>);
+  return go(quantize_rows_kernel<ARCQ_VARIANT_G32, kMode, kDyn, kSilu>);
 }
 
 int quantize_x(const void* X, const int16_t* idx, uint8_t* QX, uint8_t* SFX, int64_t M, int64_t KQ, int64_t KE, int variant,
@@ -395,7 +434,15 @@ int quantize_w(const void* W, const int16_t* idx, uint8_t* QW, uint8_t* SFW, int
 }
 int rmsnorm_quantize_x(const void* X, const void* Wn, float eps, const int16_t* idx, uint8_t* QX, uint8_t* SFX, int64_t M,
                        int64_t KQ, int64_t KE, int variant, hipStream_t stream) {
+  if (M > 0 && (reinterpret_cast<uintptr_t>(Wn) & 15) != 0)
+    return fail(ARCQ_ERR_SHAPE, "arcq_rmsnorm_quantize_x: the norm weight must be 16-byte aligned");
   return launch_quantize<kModeRms>(X, Wn, eps, idx, QX, SFX, M, KQ, KE, variant, stream, "arcq_rmsnorm_quantize_x");
+}
+
+// workgroups of the abs-max pass: ~16 chunks (256 B) per thread, at most one slot per CU
+static int absmax_grid(int64_t chunks) {
+  const int64_t want = (chunks + (int64_t)kAbsmaxThreads * 16 - 1) / ((int64_t)kAbsmaxThreads * 16);
+  return (int)(want < 1 ? 1 : (want > kAbsmaxMaxBlocks ? kAbsmaxMaxBlocks : want));
 }
 
 // Largest input (bytes) for which every workgroup recomputes max|X| itself instead of a separate abs-max launch
@@ -410,14 +457,13 @@ int quantize_x_dyn(const void* X, const int16_t* idx, uint8_t* QX, uint8_t* SFX,
   if (rc != ARCQ_OK || M <= 0) return rc;
   if (!X || !idx || !QX || !SFX) return fail(ARCQ_ERR_NULL, "arcq_quantize_x_dyn: NULL pointer");
   if ((reinterpret_cast<uintptr_t>(X) & 15) != 0) return fail(ARCQ_ERR_SHAPE, "arcq_quantize_x_dyn: X must be 16-byte aligned");
-  unsigned int* st = reinterpret_cast<unsigned int*>(state);
+  unsigned int* st = reinterpret_cast<unsigned int*>(state);     // ARCQ_DYN_STATE_BYTES of scratch, fully rewritten here
   const int64_t n = M * KQ, n8 = n / 8;
   if (n * 2 <= kDynLocalMaxBytes)     // decode-sized: one launch, `state` untouched
-    return launch_quantize<kModeX>(X, nullptr, 0.f, idx, QX, SFX, M, KQ, KE, variant, stream, "arcq_quantize_x_dyn", kDynLocal, nullptr, scale_out);
-  int64_t want = (n8 + 255) / 256;
-  const int grid = (int)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
-  hipLaunchKernelGGL(absmax_bits_kernel, dim3(grid), dim3(256), 0, stream, (const uint16_t*)X, n8, n, st);
-  return launch_quantize<kModeX>(X, nullptr, 0.f, idx, QX, SFX, M, KQ, KE, variant, stream, "arcq_quantize_x_dyn", kDynState, st, scale_out);
+    return launch_quantize<kModeX, kDynLocal>(X, nullptr, 0.f, idx, QX, SFX, M, KQ, KE, variant, stream, "arcq_quantize_x_dyn", nullptr, 0, scale_out);
+  const int grid = absmax_grid(n8);
+  hipLaunchKernelGGL(absmax_bits_kernel<false>, dim3(grid), dim3(kAbsmaxThreads), 0, stream, (const uint16_t*)X, n8, n, st);
+  return launch_quantize<kModeX, kDynState>(X, nullptr, 0.f, idx, QX, SFX, M, KQ, KE, variant, stream, "arcq_quantize_x_dyn", st, grid, scale_out);
 }
 
 // GU = [M, 2*KQ] bf16 (gate | up, the fused gate_up projection's output): quantise silu(gate) * up with its
@@ -434,10 +480,10 @@ int silu_mul_quantize_x_dyn(const void* GU, const int16_t* idx, uint8_t* QX, uin
   const uint16_t* G = reinterpret_cast<const uint16_t*>(GU);
   const uint16_t* U = G + KQ;
   const int64_t chunks = KQ / 8, total = M * chunks;
-  int64_t want = (total + 255) / 256;
-  const int grid = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
-  hipLaunchKernelGGL(silu_mul_absmax_kernel, dim3(grid), dim3(256), 0, stream, G, U, 2 * KQ, (int)M, (int)chunks, st);
-  return launch_quantize<kModeX>(G, nullptr, 0.f, idx, QX, SFX, M, KQ, KE, variant, stream, who, kDynState, st, scale_out, U, 2 * KQ);
+  // a chunk of the product costs eight exp: four chunks per thread are plenty
+  const int grid = absmax_grid(total * 4);
+  hipLaunchKernelGGL(silu_mul_absmax_kernel, dim3(grid), dim3(kAbsmaxThreads), 0, stream, G, U, 2 * KQ, (int)M, (int)chunks, st);
+  return launch_quantize<kModeX, kDynState, true>(G, nullptr, 0.f, idx, QX, SFX, M, KQ, KE, variant, stream, who, st, grid, scale_out, U, 2 * KQ);
 }
 
 int absmax_scale(const void* X, int64_t n, float* scale_out, hipStream_t stream) {
@@ -449,9 +495,7 @@ int absmax_scale(const void* X, int64_t n, float* scale_out, hipStream_t stream)
   hipError_t e = hipMemsetAsync(slot, 0, sizeof(unsigned int), stream);
   if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_absmax_scale: memset failed: %s", hipGetErrorString(e));
   const int64_t n8 = n / 8;
-  int64_t want = (n8 + 255) / 256;
-  const int grid = (int)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
-  hipLaunchKernelGGL(absmax_bits_kernel, dim3(grid), dim3(256), 0, stream, (const uint16_t*)X, n8, n, slot);
+  hipLaunchKernelGGL(absmax_bits_kernel<true>, dim3(absmax_grid(n8)), dim3(kAbsmaxThreads), 0, stream, (const uint16_t*)X, n8, n, slot);
   hipLaunchKernelGGL(absmax_finish_kernel, dim3(1), dim3(1), 0, stream, slot, scale_out);
   e = hipGetLastError();
   if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_absmax_scale: launch failed: %s", hipGetErrorString(e));

@@ -120,7 +120,7 @@ def bench_extra(args, device, rank):
     #      weights rotated through > 256 MiB so that they stream from HBM, not from the Infinity Cache
     KE = 64
     for (m, n, kq) in [(1, 4096, 4096), (4, 4096, 4096), (16, 4096, 4096), (1, 14336, 4096), (1, 4096, 14336), (1, 1024, 4096),
-                       (4, 3584, 3584), (4, 18944, 3584), (4, 3584, 18944)]:
+                       (4, 3584, 3584), (4, 18944, 3584), (4, 37888, 3584), (4, 3584, 18944)]:
         q = make_problem(m, n, kq, KE, device)
         rot = max(2, int(320e6 // (n * (kq + KE) * 9 / 16)) + 1)
         qws = [q["qw"].clone() for _ in range(rot)]
@@ -153,6 +153,25 @@ def bench_extra(args, device, rank):
         extra[f"quantize_x_{S}"] = {"us": round(tq, 2), "GBps": round(qbytes / tq / 1e3, 1)}
         del q, a16, b16, xs
     torch.cuda.empty_cache()
+    # ---- decode-batch / short-prefill token counts (split-K tiles) and the decode-step quantisers, graph-timed
+    for (m, n, kq) in [(32, 4096, 4096), (128, 4096, 4096), (64, 3584, 18944)]:
+        q = make_problem(m, n, kq, KE, device)
+        o = torch.empty((m, n), dtype=torch.bfloat16, device=device)
+        t = graph_time([lambda: agemm.matmul(q["qx"], q["qw"], q["sfx"], q["sfw"], q["alpha"], out=o)] * 4)
+        extra[f"midM_gemm_M{m}_N{n}_KQ{kq}"] = {"us_per_call_graph": round(t, 2), "TFLOPs": round(gemm_flops(m, n, kq + KE) / t / 1e6, 1),
+                                               "note": "split-K tile GEMM + finish pass, weights cache-resident"}
+        del q
+    xq = outlier_activations(4, 3584, device)
+    gu = (torch.randn(4, 2 * 18944, device=device) * 2).to(torch.bfloat16)
+    idx_h = torch.arange(3584, dtype=torch.int16, device=device)
+    idx_i = torch.arange(18944, dtype=torch.int16, device=device)
+    wn = torch.ones(3584, dtype=torch.bfloat16, device=device)
+    extra["decode_quantisers_us_graph"] = {
+        "rmsnorm_quantize_x_M4_KQ3584": round(graph_time([lambda: agemm.rmsnorm_quantize_x(xq, wn, 1e-6, idx_h, 64)] * 8), 2),
+        "reorder_quantize_x_dynamic_M4_KQ3584": round(graph_time([lambda: agemm.reorder_quantize_x_dynamic(xq, idx_h, 64)] * 8), 2),
+        "silu_mul_quantize_x_dynamic_M4_KQ18944": round(graph_time([lambda: agemm.silu_mul_quantize_x_dynamic(gu, idx_i, 64)] * 8), 2),
+        "note": "per call, HIP-graph replay; the SiLU*up variant is two launches, the others one"}
+    del xq, gu
     try:
         from arcquant_amd.e2e import bench_decode
         extra["qwen2.5-7b_decode"] = bench_decode("qwen2.5-7b", batch=4, prefill=1024, steps=16, device=device)

@@ -116,8 +116,11 @@ int arcq_absmax_scale(const void *X, int64_t n, float *scale_out, void *stream);
 
 /* NVFP4_reorder_quantize_x (model/qLlamaLayer.py:73-77) in two launches instead of five:
  *   scale = max|X| / 2688 (fp32, written to scale_out[0]);  (QX, SFX) = arcq_quantize_x(bf16(X / scale), ...).
- * `state` is 8 bytes of device memory owned by the caller that must be ZERO before the first call; every call
- * leaves it zero again (the last workgroup resets it), so no memset is needed between calls or graph replays. */
+ * `state` is ARCQ_DYN_STATE_BYTES of device scratch owned by the caller (one abs-max word per workgroup of the
+ * abs-max pass; plain stores, fully rewritten by every call, so it needs no initialisation and no reset; it must not
+ * be shared by calls that may run concurrently on different streams).  Inputs <= 256 KB take a single launch and do
+ * not touch it. */
+#define ARCQ_DYN_STATE_BYTES 1024
 int arcq_quantize_x_dyn(const void *X, const int16_t *reorder_index, uint8_t *QX, uint8_t *SFX, float *scale_out,
                         void *state, int64_t M, int64_t KQ, int64_t KE, int variant, void *stream);
 

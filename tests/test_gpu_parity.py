@@ -359,7 +359,7 @@ def test_gemm_with_subnormal_and_extreme_scales():
 def test_dynamic_quantizer_equals_torch_prescale_pipeline():
     """reorder_quantize_x_dynamic == the reference's three-step wrapper (model/qLlamaLayer.py:73-77:
     scale = max|x|/2688; x/scale in torch; reorder_quantize_x) byte for byte, for decode- and prefill-sized inputs,
-    and repeated calls keep working (the 8-byte state resets itself)."""
+    and repeated calls keep working (the abs-max scratch is rewritten by every call)."""
     ag = _agemm()
     for (M, KQ, KE) in [(4, 3584, 64), (1, 4096, 64), (300, 2048, 128), (4, 18944, 64)]:
         x = outlier_activations(M, KQ, 40 + M).to(DEV)
