@@ -480,9 +480,11 @@ int silu_mul_quantize_x_dyn(const void* GU, const int16_t* idx, uint8_t* QX, uin
   const uint16_t* G = reinterpret_cast<const uint16_t*>(GU);
   const uint16_t* U = G + KQ;
   const int64_t chunks = KQ / 8, total = M * chunks;
-  // a chunk of the product costs eight exp: four chunks per thread are plenty
-  const int grid = absmax_grid(total * 4);
-  hipLaunchKernelGGL(silu_mul_absmax_kernel, dim3(grid), dim3(kAbsmaxThreads), 0, stream, G, U, 2 * KQ, (int)M, (int)chunks, st);
+  // a chunk of the product costs eight exp: spread it as widely as the slot count allows (decode: one chunk per thread)
+  const int threads = total >= (int64_t)kAbsmaxMaxBlocks * kAbsmaxThreads ? kAbsmaxThreads : 256;
+  const int64_t want = (total + threads - 1) / threads;
+  const int grid = (int)(want > kAbsmaxMaxBlocks ? kAbsmaxMaxBlocks : want);
+  hipLaunchKernelGGL(silu_mul_absmax_kernel, dim3(grid), dim3(threads), 0, stream, G, U, 2 * KQ, (int)M, (int)chunks, st);
   return launch_quantize<kModeX, kDynState, true>(G, nullptr, 0.f, idx, QX, SFX, M, KQ, KE, variant, stream, who, st, grid, scale_out, U, 2 * KQ);
 }
 
