@@ -153,6 +153,24 @@ def bench_extra(args, device, rank):
         extra[f"quantize_x_{S}"] = {"us": round(tq, 2), "GBps": round(qbytes / tq / 1e3, 1)}
         del q, a16, b16, xs
     torch.cuda.empty_cache()
+    # ---- SURVEY 8-d sweep: token counts at N=KQ=4096 KE=64, plus KE=0 and the reference bench's K=5888 (bench_nvfp4.cu:25)
+    sweep = {}
+    for (m, n, kq, ke) in [(128, 4096, 4096, 64), (1024, 4096, 4096, 64), (8192, 4096, 4096, 64), (4096, 4096, 4096, 0),
+                           (4096, 4096, 5888, 0)]:
+        q = make_problem(m, n, kq, ke, device)
+        t = time_events(lambda: agemm.matmul(q["qx"], q["qw"], q["sfx"], q["sfw"], q["alpha"]), 30, 5)
+        sweep[f"M{m}_N{n}_KQ{kq}_KE{ke}"] = {"us": round(t, 2), "TFLOPs": round(gemm_flops(m, n, kq + ke) / t / 1e6, 1)}
+        del q
+    extra["gemm_sweep"] = sweep
+    # ---- BASELINE config[2]: the seven linears of one Llama-3-8B layer at bs=1, seqlen=1 (sum of the graph-timed launches above)
+    try:
+        c3 = (2 * extra["decode_gemm_M1_N4096_KQ4096"]["us_per_launch_graph"] + 2 * extra["decode_gemm_M1_N1024_KQ4096"]["us_per_launch_graph"]
+              + 2 * extra["decode_gemm_M1_N14336_KQ4096"]["us_per_launch_graph"] + extra["decode_gemm_M1_N4096_KQ14336"]["us_per_launch_graph"])
+        wbytes = (2 * 4096 + 2 * 1024 + 2 * 14336) * 4160 * 9 / 16 + 4096 * 14400 * 9 / 16
+        extra["llama3_8b_layer_linears_decode"] = {"us": round(c3, 2), "GBps": round(wbytes / c3 / 1e3, 1),
+                                                  "note": "q,o 4096x4096; k,v 1024x4096; gate,up 14336x4096; down 4096x14336; M=1, KE=64"}
+    except KeyError:
+        pass
     # ---- decode-batch / short-prefill token counts (split-K tiles) and the decode-step quantisers, graph-timed
     for (m, n, kq) in [(32, 4096, 4096), (128, 4096, 4096), (64, 3584, 18944)]:
         q = make_problem(m, n, kq, KE, device)
