@@ -168,6 +168,10 @@ GEMM_CASES = [
     (9, 5250, 512, 64, O.G16),        # ... ragged N, N % 4 != 0, two activation dwords per thread
     (16, 5120, 2048, 128, O.G32),     # ... four activation dwords per thread, three slabs
     (1, 6144, 256, 0, O.G16),         # ... a single short slab
+    (4, 5120, 256, 256, O.G16),       # ... KE == KQ (every channel carries a residual)
+    (4, 5120, 64, 0, O.G16),          # K = 64: a single scale atom, on each of the three kernels
+    (3, 200, 64, 0, O.G16),
+    (40, 256, 64, 0, O.G16),
 ]
 
 
@@ -444,6 +448,27 @@ def test_decode_and_tile_kernels_agree_and_full_residual_width():
     assert np.all(np.abs(big.cpu().numpy() - want) <= 2e-6 * wabs + 1e-30)
     assert np.all(np.abs(small.cpu().numpy() - want[:16]) <= 2e-6 * wabs[:16] + 1e-30)
     assert torch.allclose(big[:16], small, rtol=1e-5, atol=1e-5 * float(big.abs().max()))
+
+
+def test_gemm_epilogue_operands_on_every_kernel():
+    """bias + residual + device scale through the 16-row decode kernel, the 32-row decode kernel, the split-K tile
+    path and the 256x256 tile: the fused epilogue equals the separate torch ops on the plain result, and doubling
+    alpha doubles the fp32 output exactly (linearity in the per-tensor scale; a power of two commutes with every
+    rounding)."""
+    ag = _agemm()
+    for (M, N, KQ) in [(4, 384, 512), (4, 5120, 512), (40, 512, 1984), (300, 2048, 256)]:
+        qx, sfx, qw, sfw, alpha = _make_operands(M, N, KQ, 64, O.G16, 3 * M + N)
+        A, B = torch.from_numpy(qx).to(DEV), torch.from_numpy(qw).to(DEV)
+        SFA, SFB = torch.from_numpy(sfx).to(DEV), torch.from_numpy(sfw).to(DEV)
+        g = torch.Generator().manual_seed(N)
+        bias = torch.randn(N, generator=g).to(torch.bfloat16).to(DEV)
+        res = torch.randn(M, N, generator=g).to(torch.bfloat16).to(DEV)
+        plain32 = ag.matmul(A, B, SFA, SFB, alpha, out_dtype=torch.float32)
+        assert torch.equal(ag.matmul(A, B, SFA, SFB, 2 * alpha, out_dtype=torch.float32), 2 * plain32)
+        want = res + (plain32 + bias.float()).to(torch.bfloat16)          # bf16(alpha*acc + bias), then the bf16 add
+        dev_scale = torch.tensor(alpha / 0.5, dtype=torch.float32, device=DEV)
+        got = ag.matmul(A, B, SFA, SFB, dev_scale, scale_host=0.5, bias=bias, residual=res)
+        assert torch.equal(got, want), (M, N, KQ)
 
 
 @pytest.mark.parametrize("M,N", [(1, 1), (2, 16), (16, 17), (33, 1)])
