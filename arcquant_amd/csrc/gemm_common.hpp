@@ -43,6 +43,16 @@ __device__ __forceinline__ f16x2 sf_pair(uint32_t byte) {
   return r;
 }
 
+// The same for the scale byte at bit offset `off` of a packed word, in two instructions: v_bfe_u32 takes the seven
+// magnitude bits, one 24-bit multiply by (2^7 + 2^23) shifts them into both fp16 halves (x < 128, so the copies
+// cannot overlap).
+__device__ __forceinline__ f16x2 sf_pair_at(uint32_t word, uint32_t off) {
+  const uint32_t w = __builtin_amdgcn_ubfe(word, off, 7u) * 0x00800080u;   // both factors < 2^24: compiles to v_mul_u32_u24
+  f16x2 r;
+  __builtin_memcpy(&r, &w, 4);
+  return r;
+}
+
 // 8 e2m1 codes (one dword, low nibble first) x scale -> 8 fp16:  (code * 2^8) * (scale * 2^-8), both factors and
 // the product exact in fp16.
 __device__ __forceinline__ Frag8 dequant8(uint32_t codes, f16x2 s2) {

@@ -183,6 +183,14 @@ __global__ __launch_bounds__(kDecThreads, kADw == 1 ? 4 : 2) void gemm_decode_ke
   const int ld_atom = slab_begin * kDecSlabAtoms + (la_c >> 3);             // A loader role: atom of slab 0
   int parity = 0;
   int cur_tile = blockIdx.x, cur_slab = 0;
+  // rows of this lane beyond N contribute nothing: their scale bytes are masked to zero (per tile, not per item)
+  uint32_t nmask0 = 0, nmask1 = 0;
+  auto tile_masks = [&]() __attribute__((always_inline)) {
+    const int row0 = (cur_tile >> 2) * 128 + (cur_tile & 3) * 8 + cm_rowpart;
+    nmask0 = row0 < p.N ? 0xffffffffu : 0u;
+    nmask1 = row0 + 4 < p.N ? 0xffffffffu : 0u;
+  };
+  tile_masks();
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 
   // One item: stage `r` into LDS, refill `r` with the item three ahead, barrier, multiply; close the tile after
@@ -195,8 +203,7 @@ __global__ __launch_bounds__(kDecThreads, kADw == 1 ? 4 : 2) void gemm_decode_ke
     {
       const bool a_live = ld_atom + cur_slab * kDecSlabAtoms < atoms_k;   // false only in the partial tail slab
       auto stage_a = [&](int i, uint32_t codes, uint32_t sf4) {
-        const uint32_t sa = a_live ? (sf4 >> sa_sh) & 0xffu : 0u;
-        const Frag8 f = dequant8(codes, sf_pair(sa));
+        const Frag8 f = dequant8(codes, sf_pair_at(a_live ? sf4 : 0u, sa_sh));
         if (4 * i + la_m < p.M) *reinterpret_cast<uint4*>(buf + wra_off + 4 * i * kDecAStride) = f.u;
       };
       stage_a(0, r.a0, r.sa0);
@@ -206,10 +213,9 @@ __global__ __launch_bounds__(kDecThreads, kADw == 1 ? 4 : 2) void gemm_decode_ke
     uint32_t bs0 = r.sb0, bs1 = r.sb1;
     issue_next(r);                                             // refill: 3 items ahead
     __syncthreads();
-    const int row0 = (cur_tile >> 2) * 128 + (cur_tile & 3) * 8 + cm_rowpart;
-    const bool live = lane_atom + cur_slab * kDecSlabAtoms < atoms_k;
-    bs0 = (live && row0 < p.N) ? bs0 : 0u;
-    bs1 = (live && row0 + 4 < p.N) ? bs1 : 0u;
+    const bool live = lane_atom + cur_slab * kDecSlabAtoms < atoms_k;     // false only in the partial tail slab
+    bs0 = live ? bs0 & nmask0 : 0u;
+    bs1 = live ? bs1 & nmask1 : 0u;
     const uint4 bq0 = *reinterpret_cast<const uint4*>(buf + rdb_off);
     const uint4 bq1 = *reinterpret_cast<const uint4*>(buf + rdb_off + 16 * kDecBStride);
     Frag8 a0, a1, a2, a3;
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(kDecThreads, kADw == 1 ? 4 : 2) void gemm_decode_ke
     a3.u = *reinterpret_cast<const uint4*>(buf + rda_off + 48);
     // weights are the MFMA A operand (rows i = rho), activations the B operand (cols j = token)
     {
-      const f16x2 s0 = sf_pair((bs0 >> sh) & 0xffu), s1 = sf_pair((bs0 >> (sh + 8)) & 0xffu);
+      const f16x2 s0 = sf_pair_at(bs0, sh), s1 = sf_pair_at(bs0, sh + 8);
       const Frag8 b0 = dequant8(bq0.x, s0), b1 = dequant8(bq0.y, s0), b2 = dequant8(bq0.z, s1), b3 = dequant8(bq0.w, s1);
       acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0.v, a0.v, acc0, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1.v, a1.v, acc0, 0, 0, 0);
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(kDecThreads, kADw == 1 ? 4 : 2) void gemm_decode_ke
       acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(b3.v, a3.v, acc0, 0, 0, 0);
     }
     {
-      const f16x2 s0 = sf_pair((bs1 >> sh) & 0xffu), s1 = sf_pair((bs1 >> (sh + 8)) & 0xffu);
+      const f16x2 s0 = sf_pair_at(bs1, sh), s1 = sf_pair_at(bs1, sh + 8);
       const Frag8 b0 = dequant8(bq1.x, s0), b1 = dequant8(bq1.y, s0), b2 = dequant8(bq1.z, s1), b3 = dequant8(bq1.w, s1);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0.v, a0.v, acc1, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1.v, a1.v, acc1, 0, 0, 0);
@@ -265,6 +271,7 @@ __global__ __launch_bounds__(kDecThreads, kADw == 1 ? 4 : 2) void gemm_decode_ke
       // `red` is next written after at least one more __syncthreads (the next tile's first item), so no barrier here
       cur_slab = 0;
       cur_tile += G;
+      tile_masks();
       acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
       acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
     }

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gemm_skinny_kernel(SkinnyParam
       if (a_loader) {
         // dequantise this thread's 32 activations once for the whole workgroup (cost scales with M, not 16)
         const uint32_t sa = ld_atom + cur_slab * kSlabAtoms < atoms_k ? r0.sa : 0u;
-        const f16x2 s0 = sf_pair(sa & 0xffu), s1 = sf_pair((sa >> 8) & 0xffu);
+        const f16x2 s0 = sf_pair_at(sa, 0), s1 = sf_pair_at(sa, 8);
         Frag8 f0 = dequant8(r0.a.x, s0), f1 = dequant8(r0.a.y, s0), f2 = dequant8(r0.a.z, s1), f3 = dequant8(r0.a.w, s1);
         *reinterpret_cast<uint4*>(buf + wra_off + ((0 ^ wra_swz) << 4)) = f0.u;
         *reinterpret_cast<uint4*>(buf + wra_off + ((1 ^ wra_swz) << 4)) = f1.u;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gemm_skinny_kernel(SkinnyParam
       a1.u = *reinterpret_cast<const uint4*>(buf + rda_off + ((1 ^ rda_swz) << 4));
       a2.u = *reinterpret_cast<const uint4*>(buf + rda_off + ((2 ^ rda_swz) << 4));
       a3.u = *reinterpret_cast<const uint4*>(buf + rda_off + ((3 ^ rda_swz) << 4));
-      const f16x2 sb0 = sf_pair((bs >> sh) & 0xffu), sb1 = sf_pair((bs >> (sh + 8)) & 0xffu);
+      const f16x2 sb0 = sf_pair_at(bs, sh), sb1 = sf_pair_at(bs, sh + 8);
       Frag8 b0 = dequant8(bq.x, sb0), b1 = dequant8(bq.y, sb0), b2 = dequant8(bq.z, sb1), b3 = dequant8(bq.w, sb1);
       // weights are the MFMA A operand (rows i = rho), activations the B operand (cols j = token)
       acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0.v, a0.v, acc, 0, 0, 0);

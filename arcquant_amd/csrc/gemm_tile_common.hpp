@@ -59,7 +59,7 @@ __device__ __forceinline__ Staged stage_load(const uint8_t* __restrict__ qrow, c
 
 __device__ __forceinline__ void stage_store(unsigned char* tile, const int (&slot)[4], const Staged& s, uint32_t live_mask) {
   const uint32_t sf = s.sf & live_mask;
-  const f16x2 s0 = sf_pair(sf & 0xffu), s1 = sf_pair((sf >> 8) & 0xffu);
+  const f16x2 s0 = sf_pair_at(sf, 0), s1 = sf_pair_at(sf, 8);
   Frag8 f0 = dequant8(s.q.x, s0), f1 = dequant8(s.q.y, s0), f2 = dequant8(s.q.z, s1), f3 = dequant8(s.q.w, s1);
   *reinterpret_cast<uint4*>(tile + slot[0]) = f0.u;
   *reinterpret_cast<uint4*>(tile + slot[1]) = f1.u;
