@@ -85,8 +85,8 @@ class DecoderModel:
                    dict(q=QLinear(h, h, ke, device, g), k=QLinear(h, h, ke, device, g), v=QLinear(h, h, ke, device, g),
                         gate=QLinear(h, it, ke, device, g), up=QLinear(h, it, ke, device, g))),
                 o=QLinear(h, h, ke, device, g), down=QLinear(it, h, ke, device, g),
-                kc=torch.zeros(batch, cfg.num_heads, max_len, h // cfg.num_heads, dtype=torch.bfloat16, device=device),
-                vc=torch.zeros(batch, cfg.num_heads, max_len, h // cfg.num_heads, dtype=torch.bfloat16, device=device)))
+                kv=torch.zeros(2, batch, cfg.num_heads, max_len, h // cfg.num_heads, dtype=torch.bfloat16, device=device)))
+            self.layers[-1]["kc"], self.layers[-1]["vc"] = self.layers[-1]["kv"][0], self.layers[-1]["kv"][1]
         self.idx_h = torch.arange(h, dtype=torch.int16, device=device)
         self.idx_i = torch.arange(it, dtype=torch.int16, device=device)
         self.norm = torch.ones(h, dtype=torch.bfloat16, device=device)
@@ -122,8 +122,11 @@ class DecoderModel:
                 k = agemm.matmul(A, L["k"].W, SFA, L["k"].SFW, L["k"].scale)
                 v = agemm.matmul(A, L["v"].W, SFA, L["v"].SFW, L["v"].scale)
             q = q.reshape(bsz, q_len, nh, hd).transpose(1, 2)
-            L["kc"][:, :, pos:pos + q_len] = k.reshape(bsz, q_len, nh, hd).transpose(1, 2)
-            L["vc"][:, :, pos:pos + q_len] = v.reshape(bsz, q_len, nh, hd).transpose(1, 2)
+            if self.fused:      # k|v are adjacent columns of the fused projection: ONE strided copy appends both to the cache
+                L["kv"][:, :, :, pos:pos + q_len] = qkv[:, h:].reshape(bsz, q_len, 2, nh, hd).permute(2, 0, 3, 1, 4)
+            else:
+                L["kc"][:, :, pos:pos + q_len] = k.reshape(bsz, q_len, nh, hd).transpose(1, 2)
+                L["vc"][:, :, pos:pos + q_len] = v.reshape(bsz, q_len, nh, hd).transpose(1, 2)
             if self.attention == "cache":
                 att = F.scaled_dot_product_attention(q, L["kc"][:, :, :pos + q_len], L["vc"][:, :, :pos + q_len],
                                                      is_causal=(q_len > 1 and pos == 0))
