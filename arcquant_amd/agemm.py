@@ -175,7 +175,7 @@ def absmax_scale(X: torch.Tensor) -> torch.Tensor:
 _dyn_state = {}
 
 
-def _quantize_dynamic(entry: str, who: str, X: torch.Tensor, KQ: int, reorder_index: torch.Tensor, KE: int, variant):
+def _quantize_dynamic(entry: str, who: str, X: torch.Tensor, KQ: int, reorder_index: torch.Tensor, KE: int, variant, slots=None):
     _need(reorder_index, torch.int16, "reorder_index", 1)
     M = X.shape[0]
     KE = int(KE)
@@ -193,17 +193,54 @@ def _quantize_dynamic(entry: str, who: str, X: torch.Tensor, KQ: int, reorder_in
     SFX = torch.empty((sf_buffer_bytes(M, K),), dtype=torch.uint8, device=dev)
     scale = torch.empty((1,), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        st = getattr(_lib.lib(), entry)(X.data_ptr(), reorder_index.data_ptr(), QX.data_ptr(), SFX.data_ptr(), scale.data_ptr(),
-                                        state.data_ptr(), M, KQ, KE, int(variant), _stream(X))
+        if slots is not None:
+            st = getattr(_lib.lib(), entry)(X.data_ptr(), reorder_index.data_ptr(), QX.data_ptr(), SFX.data_ptr(), scale.data_ptr(),
+                                            slots.data_ptr(), slots.numel(), M, KQ, KE, int(variant), _stream(X))
+        else:
+            st = getattr(_lib.lib(), entry)(X.data_ptr(), reorder_index.data_ptr(), QX.data_ptr(), SFX.data_ptr(), scale.data_ptr(),
+                                            state.data_ptr(), M, KQ, KE, int(variant), _stream(X))
     _lib.check(st, who)
     return QX, SFX, scale.reshape(())
 
 
-def reorder_quantize_x_dynamic(X: torch.Tensor, reorder_index: torch.Tensor, KE: int, variant=None):
+def matmul_silu_mul(A: torch.Tensor, B: torch.Tensor, SFA: torch.Tensor, SFB: torch.Tensor, scale, *, scale_host: float = 1.0):
+    """Extension: the gate|up GEMM with the MLP's ``act_fn(gate) * up`` (SiLU, model/qLlamaLayer.py:417) in
+    its epilogue.  ``B`` is the quantised weight whose ROWS INTERLEAVE gate and up (g0, u0, g1, u1, ...).  Returns
+    ``(act, absmax_slots)``: ``act`` bf16 [M, N/2] equals ``F.silu(y[:, 0::2]) * y[:, 1::2]`` of ``y = matmul(A, B, ...)``
+    bit for bit; ``absmax_slots`` feeds ``reorder_quantize_x_dynamic(act, ..., absmax_slots=...)`` (one launch)."""
+    _need(A, torch.uint8, "A", 2)
+    _need(B, torch.uint8, "B", 2)
+    _need(SFA, torch.uint8, "SFA")
+    _need(SFB, torch.uint8, "SFB")
+    M, N, K = A.shape[0], B.shape[0], A.shape[1] * 2
+    if B.shape[1] != A.shape[1] or K % 64 or N % 8:
+        raise RuntimeError(f"Value error in matmul_silu_mul: A {tuple(A.shape)} / B {tuple(B.shape)} need equal K, K % 64 == 0, N % 8 == 0")
+    if SFA.numel() < _lib.lib().arcq_sf_used_bytes(M, K) or SFB.numel() < _lib.lib().arcq_sf_used_bytes(N, K):
+        raise RuntimeError("Value error in matmul_silu_mul: scale buffer too small")
+    alpha_host, alpha_dev = float(scale_host), None
+    if isinstance(scale, torch.Tensor) and scale.is_cuda:
+        alpha_dev = scale.reshape(-1)[:1].to(torch.float32)
+    else:
+        alpha_host *= float(scale)
+    L = _lib.lib()
+    act = torch.empty((M, N // 2), dtype=torch.bfloat16, device=A.device)
+    slots = torch.empty((max(1, int(L.arcq_gemm_silu_mul_slots(M, N, K))),), dtype=torch.int32, device=A.device)
+    with torch.cuda.device(A.device):
+        st = L.arcq_gemm_nvfp4_silu_mul(A.data_ptr(), B.data_ptr(), SFA.data_ptr(), SFB.data_ptr(), act.data_ptr(), slots.data_ptr(), M, N, K,
+                                        alpha_host, alpha_dev.data_ptr() if alpha_dev is not None else None, _stream(A))
+    _lib.check(st, "matmul_silu_mul")
+    return act, slots
+
+
+def reorder_quantize_x_dynamic(X: torch.Tensor, reorder_index: torch.Tensor, KE: int, variant=None, absmax_slots=None):
     """Extension: ``NVFP4_reorder_quantize_x`` (model/qLlamaLayer.py:73-77) without a host sync, in ONE launch
     for decode-sized inputs (<= 256 KB) and two otherwise: returns (QX, SFX, scale) with ``scale = max|X|/2688`` a 0-dim
     fp32 device tensor and (QX, SFX) byte-identical to ``reorder_quantize_x(X / scale, reorder_index, KE)``."""
     _need(X, torch.bfloat16, "X", 2)
+    if absmax_slots is not None:           # max|X| already known per workgroup (matmul_silu_mul): one launch for any size
+        _need(absmax_slots, torch.int32, "absmax_slots", 1)
+        return _quantize_dynamic("arcq_quantize_x_dyn_slots", "reorder_quantize_x_dynamic", X, X.shape[1], reorder_index, KE, variant,
+                                 slots=absmax_slots)
     return _quantize_dynamic("arcq_quantize_x_dyn", "reorder_quantize_x_dynamic", X, X.shape[1], reorder_index, KE, variant)
 
 

@@ -58,4 +58,14 @@ __host__ __device__ __forceinline__ int64_t sf_offset(int64_t r, int64_t p, int6
   return ((r >> 7) * (K >> 6) + (p >> 2)) * 512 + (r & 31) * 16 + ((r >> 5) & 3) * 4 + (p & 3);
 }
 
+// act = silu(gate) * up on bf16 bits, rounded where torch's two elementwise kernels round (model/qLlamaLayer.py:
+// `self.act_fn(gate) * up`): silu in fp32 as x / (1 + exp(-x)) -> bf16 (ActivationSiluKernel), then the fp32 product
+// -> bf16 (MulFunctor).  expf / the division are the same ocml / IEEE operations torch's HIP build uses.
+__device__ __forceinline__ uint32_t silu_mul_bf16(uint32_t g_bits, uint32_t u_bits) {
+  const float g = bf16_bits_to_f32(g_bits);
+  const float s = g / (1.0f + expf(-g));
+  const float sb = bf16_bits_to_f32(f32_to_bf16_bits(s));
+  return f32_to_bf16_bits(sb * bf16_bits_to_f32(u_bits));
+}
+
 }  // namespace arcq

@@ -20,6 +20,8 @@ int rmsnorm_quantize_x(const void* X, const void* Wn, float eps, const int16_t* 
 int absmax_scale(const void* X, int64_t n, float* scale_out, hipStream_t stream);
 int quantize_x_dyn(const void* X, const int16_t* idx, uint8_t* QX, uint8_t* SFX, float* scale_out, void* state, int64_t M,
                    int64_t KQ, int64_t KE, int variant, hipStream_t stream);
+int quantize_x_dyn_slots(const void* X, const int16_t* idx, uint8_t* QX, uint8_t* SFX, float* scale_out, const uint32_t* slots,
+                         int64_t nslots, int64_t M, int64_t KQ, int64_t KE, int variant, hipStream_t stream);
 int silu_mul_quantize_x_dyn(const void* GU, const int16_t* idx, uint8_t* QX, uint8_t* SFX, float* scale_out, void* state, int64_t M,
                             int64_t KQ, int64_t KE, int variant, hipStream_t stream);
 
@@ -38,9 +40,15 @@ struct GemmArgs {
   int out_dtype;
   void* workspace;
   int64_t workspace_bytes;
+  int epilogue = 0;                  // kEpiPlain, or kEpiSiluMul: D = bf16 [M, N/2] silu(gate)*up of interleaved weight rows
+  unsigned int* absmax_slots = nullptr;   // kEpiSiluMul: one max|D| word per workgroup / tile (see gemm_silu_slots)
 };
+enum : int { kEpiPlain = 0, kEpiSiluMul = 1 };
+int64_t gemm_silu_slots(int64_t M, int64_t N, int64_t K);   // slots the silu-mul epilogue of this shape writes
 int64_t gemm_skinny_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int64_t gemm_tile_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int64_t gemm_tile_silu_slots(int64_t M, int64_t N, int64_t K);
+int64_t gemm_decode_silu_slots(int64_t M, int64_t N, int64_t K);
 // D = epilogue(sum_s partial[s]) over the `splitk` fp32 planes [M, N] at a.workspace, summed in a fixed order
 int gemm_splitk_finish(const GemmArgs& a, int splitk, hipStream_t stream);
 int gemm_skinny(const GemmArgs& a, hipStream_t stream);   // M <= 16, few tiles: weight-streaming MFMA GEMV, 16-row tiles

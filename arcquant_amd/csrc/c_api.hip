@@ -125,4 +125,39 @@ int arcq_gemm_nvfp4(const uint8_t* A, const uint8_t* B, const uint8_t* SFA, cons
   return gemm_tile(a, (hipStream_t)stream);
 }
 
+int64_t arcq_gemm_silu_mul_slots(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  return M <= kSkinnyMaxM ? gemm_decode_silu_slots(M, N, K) : gemm_tile_silu_slots(M, N, K);
+}
+
+int arcq_gemm_nvfp4_silu_mul(const uint8_t* A, const uint8_t* B, const uint8_t* SFA, const uint8_t* SFB, void* ACT, uint32_t* absmax_slots,
+                             int64_t M, int64_t N, int64_t K, float alpha_host, const float* alpha_dev, void* stream) {
+  const char* who = "arcq_gemm_nvfp4_silu_mul";
+  if (M < 0 || N < 0 || K <= 0 || (K % 64) || (N % 8))
+    return fail(ARCQ_ERR_SHAPE, "%s: need M,N >= 0, K %% 64 == 0 and N %% 8 == 0 (M=%lld N=%lld K=%lld)", who, (long long)M, (long long)N,
+                (long long)K);
+  if (M == 0 || N == 0) return ARCQ_OK;
+  if (!A || !B || !SFA || !SFB || !ACT || !absmax_slots) return fail(ARCQ_ERR_NULL, "%s: NULL pointer", who);
+  if (M > INT32_MAX / 2 || N > INT32_MAX / 2 || K > INT32_MAX / 2 || M * N > ((int64_t)1 << 40))
+    return fail(ARCQ_ERR_UNSUPPORTED, "%s: shape too large", who);
+  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(ACT)) & 15)
+    return fail(ARCQ_ERR_SHAPE, "%s: A, B and ACT must be 16-byte aligned", who);
+  if ((reinterpret_cast<uintptr_t>(SFA) | reinterpret_cast<uintptr_t>(SFB) | reinterpret_cast<uintptr_t>(absmax_slots)) & 3)
+    return fail(ARCQ_ERR_SHAPE, "%s: SFA, SFB and absmax_slots must be 4-byte aligned", who);
+  GemmArgs a;
+  a.A = A; a.B = B; a.SFA = SFA; a.SFB = SFB; a.D = ACT;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K;
+  a.alpha_host = alpha_host; a.alpha_dev = alpha_dev; a.bias = nullptr; a.residual = nullptr; a.out_dtype = ARCQ_OUT_BF16;
+  a.workspace = nullptr; a.workspace_bytes = 0;
+  a.epilogue = kEpiSiluMul; a.absmax_slots = absmax_slots;
+  // the 16-row decode kernel has no fused epilogue: every M <= 16 shape takes the 32-row kernel here
+  if (M <= kSkinnyMaxM) return gemm_decode(a, (hipStream_t)stream);
+  return gemm_tile(a, (hipStream_t)stream);
+}
+
+int arcq_quantize_x_dyn_slots(const void* X, const int16_t* reorder_index, uint8_t* QX, uint8_t* SFX, float* scale_out,
+                              const uint32_t* absmax_slots, int64_t nslots, int64_t M, int64_t KQ, int64_t KE, int variant, void* stream) {
+  return quantize_x_dyn_slots(X, reorder_index, QX, SFX, scale_out, absmax_slots, nslots, M, KQ, KE, variant, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -51,6 +51,8 @@ struct DecodeParams {
   int out_dtype;
   int tiles;              // 32-row tiles: ceil(N / 128) * 4
   int slabs_per_split;
+  int epi;                // kEpiPlain | kEpiSiluMul (interleaved gate/up rows -> D = bf16 [M, N/2], slots[tile] = max |D|)
+  unsigned int* slots;
 };
 
 constexpr int kDecWaves = 8, kDecThreads = kDecWaves * 64;
@@ -257,7 +259,22 @@ __global__ __launch_bounds__(kDecThreads, kADw == 1 ? 4 : 2) void gemm_decode_ke
         }
         // rho = 4q + e of block b is row 32q + 8t + 4b + e of the super-tile: 8 consecutive columns per lane
         const int nn = (cur_tile >> 2) * 128 + (cur_tile & 3) * 8 + q * 32;
-        if (m_ok) {
+        if (p.epi == kEpiSiluMul) {
+          // columns nn..nn+7 = four (gate, up) pairs -> four activations of token rl; never split (launcher); N % 8 == 0
+          uint32_t mx = 0;
+          if (m_ok && nn < p.N) {
+            const uint32_t a0 = silu_mul_bf16(f32_to_bf16_bits(alpha * s0[0]), f32_to_bf16_bits(alpha * s0[1]));
+            const uint32_t a1 = silu_mul_bf16(f32_to_bf16_bits(alpha * s0[2]), f32_to_bf16_bits(alpha * s0[3]));
+            const uint32_t a2 = silu_mul_bf16(f32_to_bf16_bits(alpha * s1[0]), f32_to_bf16_bits(alpha * s1[1]));
+            const uint32_t a3 = silu_mul_bf16(f32_to_bf16_bits(alpha * s1[2]), f32_to_bf16_bits(alpha * s1[3]));
+            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.D) + ((uint32_t)rl * (uint32_t)(p.N >> 1) + (uint32_t)(nn >> 1))) =
+                make_uint2(a0 | (a1 << 16), a2 | (a3 << 16));
+            mx = max(max(a0 & 0x7fffu, a1 & 0x7fffu), max(a2 & 0x7fffu, a3 & 0x7fffu));
+          }
+#pragma unroll
+          for (int sh2 = 32; sh2 > 0; sh2 >>= 1) mx = max(mx, (uint32_t)__shfl_down((int)mx, sh2, 64));
+          if (lane == 0) p.slots[cur_tile] = mx;
+        } else if (m_ok) {
           if (gridDim.y == 1) {
             if (nn < p.N) finish4<uint32_t>(p, alpha, rl, nn, s0);
             if (nn + 4 < p.N) finish4<uint32_t>(p, alpha, rl, nn + 4, s1);
@@ -326,9 +343,18 @@ static int launch_decode(const DecodeParams& p, int splitk, hipStream_t stream) 
   return ARCQ_OK;
 }
 
+int64_t gemm_decode_silu_slots(int64_t M, int64_t N, int64_t K) {
+  (void)M; (void)K;
+  return ((N + 127) / 128) * 4;              // one per 32-row tile
+}
+
 int gemm_decode(const GemmArgs& a, hipStream_t stream) {
   int splitk, per;
   decode_split(a.N, a.K, &splitk, &per);
+  if (a.epilogue == kEpiSiluMul) {             // the fused epilogue needs whole sums: one split, all slabs
+    splitk = 1;
+    per = (int)((a.K + kDecSlabK - 1) / kDecSlabK);
+  }
   DecodeParams p;
   p.A = a.A; p.B = a.B; p.SFA = a.SFA; p.SFB = a.SFB; p.D = a.D;
   p.partial = reinterpret_cast<float*>(a.workspace);
@@ -336,6 +362,7 @@ int gemm_decode(const GemmArgs& a, hipStream_t stream) {
   p.M = a.M; p.N = a.N; p.K = a.K; p.alpha_host = a.alpha_host; p.out_dtype = a.out_dtype;
   p.tiles = ((a.N + 127) / 128) * 4;
   p.slabs_per_split = per;
+  p.epi = a.epilogue; p.slots = a.absmax_slots;
   if (splitk > 1) {
     const int64_t need = (int64_t)splitk * a.M * a.N * (int64_t)sizeof(float);
     if (!a.workspace || a.workspace_bytes < need)

@@ -194,8 +194,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
   //      32x32 tiles: lane holds D[m = +(lane & 31)][n = +8*g + 4*(lane >> 5) + r], g = 0..3, r = 0..3.
   const float alpha = p.alpha_host * (p.alpha_dev ? *p.alpha_dev : 1.0f);
   const bool vec_ok = (p.N & 3) == 0;
+  uint32_t act_max = 0;                       // kEpiSiluMul: max |act| of this thread, as bf16 magnitude bits
   auto store4 = [&](int m, int n, float d0, float d1, float d2, float d3) {
     if (m >= p.M || n >= p.N) return;
+    if (p.epi == kEpiSiluMul) {               // columns n..n+3 = (gate_j, up_j, gate_j+1, up_j+1), j = n / 2; N % 4 == 0
+      const uint32_t a0 = silu_mul_bf16(f32_to_bf16_bits(alpha * d0), f32_to_bf16_bits(alpha * d1));
+      const uint32_t a1 = silu_mul_bf16(f32_to_bf16_bits(alpha * d2), f32_to_bf16_bits(alpha * d3));
+      *reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(p.D) + (size_t)m * (p.N >> 1) + (n >> 1)) = a0 | (a1 << 16);
+      act_max = max(act_max, max(a0 & 0x7fffu, a1 & 0x7fffu));
+      return;
+    }
     if (p.splits > 1) {                       // raw partial sums; the launcher only splits when N % 4 == 0
       *reinterpret_cast<float4*>(p.partial + ((size_t)split * p.M + m) * p.N + n) = make_float4(d0, d1, d2, d3);
       return;
@@ -241,6 +249,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
       }
     }
   }
+  if (p.epi == kEpiSiluMul) {                 // workgroup-uniform
+    __shared__ uint32_t wave_max[WAVES_M * WAVES_N];
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) act_max = max(act_max, (uint32_t)__shfl_down((int)act_max, sh, 64));
+    if (lane == 0) wave_max[wave] = act_max;
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t m = 0;
+#pragma unroll
+      for (int w = 0; w < WAVES_M * WAVES_N; ++w) m = max(m, wave_max[w]);
+      p.slots[blockIdx.x] = m;
+    }
+  }
 }
 
 // Split-K factor of a tile shape: split while the tiles alone leave CUs idle, keeping >= 8 atoms (512 K elements)
@@ -265,7 +286,8 @@ static int launch_tile(const GemmArgs& a, hipStream_t stream, bool allow_split =
   p.tiles_m = (a.M + BM - 1) / BM;
   p.tiles_n = (a.N + BN - 1) / BN;
   p.splits = 1; p.atoms_per_split = a.K / 64; p.partial = nullptr;
-  if (allow_split) {
+  p.epi = a.epilogue; p.slots = a.absmax_slots;
+  if (allow_split && a.epilogue == kEpiPlain) {
     tile_split(a.M, a.N, a.K, BM, BN, &p.splits, &p.atoms_per_split);
     if (p.splits > 1) {
       const int64_t need = (int64_t)p.splits * a.M * a.N * (int64_t)sizeof(float);
@@ -310,16 +332,34 @@ static TileKind tile_kind(int64_t M, int64_t N) {
   return kTile128;
 }
 
+static int effective_tile_kind(int64_t M, int64_t N) {
+  switch (tile_cfg_override()) {            // tuning override: the forced tile
+    case 0: return (int)tile_kind(M, N);
+    case 1: case 6: case 9: return kTile128;
+    case 7: return kTile64;
+    case 8: return kTile32;
+    case 4: return -4;                      // 128 x 256
+    default: return kTile256;
+  }
+}
+
+// workgroups (= abs-max slots) of the silu-mul epilogue, which never splits K
+int64_t gemm_tile_silu_slots(int64_t M, int64_t N, int64_t K) {
+  (void)K;
+  int bm = 256, bn = 256;
+  switch (effective_tile_kind(M, N)) {
+    case kTile128: bm = 128; bn = 128; break;
+    case kTile64: bm = 64; bn = 256; break;
+    case kTile32: bm = 32; bn = 256; break;
+    case -4: bm = 128; bn = 256; break;
+    default: break;
+  }
+  return ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+}
+
 int64_t gemm_tile_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   int s = 1, per = 0;
-  int kind = (int)tile_kind(M, N);
-  switch (tile_cfg_override()) {            // tuning override: the split of the forced tile
-    case 0: break;
-    case 1: kind = kTile128; break;
-    case 7: kind = kTile64; break;
-    case 8: kind = kTile32; break;
-    default: kind = kTile256; break;
-  }
+  const int kind = effective_tile_kind(M, N);
   switch (kind) {
     case kTile128: tile_split(M, N, K, 128, 128, &s, &per); break;
     case kTile64: tile_split(M, N, K, 64, 256, &s, &per); break;

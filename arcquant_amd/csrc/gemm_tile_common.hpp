@@ -26,6 +26,10 @@ struct TileParams {
   // atoms [split*atoms_per_split, +atoms_per_split) and writes raw fp32 sums to partial[split][M][N]
   int splits, atoms_per_split;
   float* partial;
+  // epilogue ARCQ_EPI_SILU_MUL: weight rows interleave gate and up (g0,u0,g1,u1,...), D is the bf16 [M, N/2] tensor
+  // silu(gate)*up and slots[blockIdx.x] receives this workgroup's max |D| (bit pattern) for the dynamic quantiser
+  int epi;
+  unsigned int* slots;
 };
 
 constexpr int kBK = 64;                 // K elements per step = one scale-factor atom column (4 groups)

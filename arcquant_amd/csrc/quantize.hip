@@ -85,15 +85,6 @@ __device__ __forceinline__ GroupQ quantize_group(float (&v)[16]) {
   return g;
 }
 
-// act = silu(gate) * up on bf16 bits, rounded where torch's two elementwise kernels round (model/qLlamaLayer.py:
-// `self.act_fn(gate) * up`): silu in fp32 as x / (1 + exp(-x)) -> bf16 (ActivationSiluKernel), then the fp32 product
-// -> bf16 (MulFunctor).  expf / the division are the same ocml / IEEE operations torch's HIP build uses.
-__device__ __forceinline__ uint32_t silu_mul_bf16(uint32_t g_bits, uint32_t u_bits) {
-  const float g = bf16_bits_to_f32(g_bits);
-  const float s = g / (1.0f + expf(-g));
-  const float sb = bf16_bits_to_f32(f32_to_bf16_bits(s));
-  return f32_to_bf16_bits(sb * bf16_bits_to_f32(u_bits));
-}
 __device__ __forceinline__ uint4 silu_mul_chunk(const uint4 g, const uint4 u) {
   const uint32_t gw[4] = {g.x, g.y, g.z, g.w}, uw[4] = {u.x, u.y, u.z, u.w};
   uint32_t o[4];
@@ -464,6 +455,14 @@ int quantize_x_dyn(const void* X, const int16_t* idx, uint8_t* QX, uint8_t* SFX,
   const int grid = absmax_grid(n8);
   hipLaunchKernelGGL(absmax_bits_kernel<false>, dim3(grid), dim3(kAbsmaxThreads), 0, stream, (const uint16_t*)X, n8, n, st);
   return launch_quantize<kModeX, kDynState>(X, nullptr, 0.f, idx, QX, SFX, M, KQ, KE, variant, stream, "arcq_quantize_x_dyn", st, grid, scale_out);
+}
+
+// The abs-max words were produced elsewhere (the silu-mul GEMM epilogue): one quantiser launch.
+int quantize_x_dyn_slots(const void* X, const int16_t* idx, uint8_t* QX, uint8_t* SFX, float* scale_out, const uint32_t* slots,
+                         int64_t nslots, int64_t M, int64_t KQ, int64_t KE, int variant, hipStream_t stream) {
+  const char* who = "arcq_quantize_x_dyn_slots";
+  if (!scale_out || !slots || nslots <= 0 || nslots > INT32_MAX) return fail(ARCQ_ERR_NULL, "%s: NULL scale_out / absmax_slots, or no slots", who);
+  return launch_quantize<kModeX, kDynState>(X, nullptr, 0.f, idx, QX, SFX, M, KQ, KE, variant, stream, who, slots, (int)nslots, scale_out);
 }
 
 // GU = [M, 2*KQ] bf16 (gate | up, the fused gate_up projection's output): quantise silu(gate) * up with its

@@ -68,7 +68,8 @@ class QLinear:
 class DecoderModel:
     """fused=False: the reference's call structure (model/qLlamaLayer.py: separate q/k/v and gate/up GEMMs, torch
     abs/max/div before each activation quantise, torch residual adds).  fused=True: q|k|v and gate|up as one GEMM each,
-    `reorder_quantize_x_dynamic` (2 launches instead of 5), residual add in the GEMM epilogue."""
+    `reorder_quantize_x_dynamic` (1-2 launches instead of 5), SiLU*up in the gate|up GEMM epilogue (`matmul_silu_mul`),
+    residual add in the GEMM epilogue, one strided K|V cache append."""
 
     def __init__(self, cfg: ModelConfig, batch: int, max_len: int, device, fused: bool = False, attention: str = "current"):
         """attention="current": what benchmarks/modeling_arc.py:169-198 times -- K/V are appended to the cache and each
@@ -142,8 +143,9 @@ class DecoderModel:
                 hcur = hcur + agemm.matmul(qa, L["o"].W, sfa, L["o"].SFW, sa * L["o"].scale)
             A, SFA = agemm.rmsnorm_quantize_x(hcur, L["ln2"], cfg.eps, self.idx_h, cfg.select_num)
             if self.fused:
-                gu = agemm.matmul(A, L["gateup"].W, SFA, L["gateup"].SFW, L["gateup"].scale)
-                qa, sfa, sa = agemm.silu_mul_quantize_x_dynamic(gu, self.idx_i, cfg.select_num)   # act_fn(gate) * up, fused
+                # gate and up rows interleaved in one weight: act_fn(gate) * up in the GEMM epilogue, its abs-max with it
+                act, slots = agemm.matmul_silu_mul(A, L["gateup"].W, SFA, L["gateup"].SFW, L["gateup"].scale)
+                qa, sfa, sa = agemm.reorder_quantize_x_dynamic(act, self.idx_i, cfg.select_num, absmax_slots=slots)
                 hcur = agemm.matmul(qa, L["down"].W, sfa, L["down"].SFW, sa, scale_host=L["down"].scale_f, residual=hcur)
             else:
                 gate = agemm.matmul(A, L["gate"].W, SFA, L["gate"].SFW, L["gate"].scale)

@@ -131,6 +131,22 @@ int arcq_quantize_x_dyn(const void *X, const int16_t *reorder_index, uint8_t *QX
 int arcq_silu_mul_quantize_x_dyn(const void *GU, const int16_t *reorder_index, uint8_t *QX, uint8_t *SFX, float *scale_out,
                                  void *state, int64_t M, int64_t KQ, int64_t KE, int variant, void *stream);
 
+/* ---- f3 extension: the MLP's `act_fn(gate) * up` (SiLU, model/qLlamaLayer.py:417) in the GEMM epilogue -------------
+ * B holds the gate and up projections with their ROWS INTERLEAVED (g0, u0, g1, u1, ...: quantise the interleaved
+ * weight with arcq_quantize_w as usual), N = 2 * intermediate, N % 8 == 0.  ACT = bf16 [M, N/2] receives
+ * silu(bf16(alpha * gate)) * bf16(alpha * up) with torch's roundings (the value `act_fn(gate) * up` has after two
+ * separate GEMMs), and absmax_slots[0 .. arcq_gemm_silu_mul_slots(M,N,K)) one max|ACT| word each (bf16 magnitude
+ * bits; plain stores, no initialisation needed).  arcq_quantize_x_dyn_slots then quantises ACT with its per-tensor
+ * dynamic scale in ONE launch: together two launches replace GEMM + silu + mul + abs-max + quantise. */
+int64_t arcq_gemm_silu_mul_slots(int64_t M, int64_t N, int64_t K);
+int arcq_gemm_nvfp4_silu_mul(const uint8_t *A, const uint8_t *B, const uint8_t *SFA, const uint8_t *SFB, void *ACT,
+                             uint32_t *absmax_slots, int64_t M, int64_t N, int64_t K, float alpha_host,
+                             const float *alpha_dev, void *stream);
+/* arcq_quantize_x_dyn with max|X| taken from `nslots` precomputed words instead of an abs-max pass. */
+int arcq_quantize_x_dyn_slots(const void *X, const int16_t *reorder_index, uint8_t *QX, uint8_t *SFX, float *scale_out,
+                              const uint32_t *absmax_slots, int64_t nslots, int64_t M, int64_t KQ, int64_t KE,
+                              int variant, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -450,6 +450,39 @@ def test_decode_and_tile_kernels_agree_and_full_residual_width():
     assert torch.allclose(big[:16], small, rtol=1e-5, atol=1e-5 * float(big.abs().max()))
 
 
+def test_silu_mul_gemm_epilogue_equals_the_unfused_steps():
+    """matmul_silu_mul on row-interleaved gate/up weights == matmul, then torch's silu and mul, bit for bit; its abs-max
+    slots give the dynamic quantiser the same scale and bytes as the abs-max pass (decode kernel, 64-row, 128x128 and
+    256x256 tiles)."""
+    import torch.nn.functional as F
+    ag = _agemm()
+    for (M, IT, KQ) in [(4, 2560, 512), (3, 136, 256), (40, 256, 512), (300, 512, 256), (3072, 2048, 256)]:
+        g = torch.Generator().manual_seed(M + IT)
+        x, sx = prescale(outlier_activations(M, KQ, 5 + M))
+        w = ((torch.rand(2 * IT, KQ, generator=g) * 2 - 1.0)).to(torch.bfloat16)          # rows: g0, u0, g1, u1, ...
+        w, sw = prescale(w)
+        idx = random_perm(KQ, 6).to(DEV)
+        qx, sfx = ag.reorder_quantize_x(x.to(DEV), idx, 64)
+        qw, sfw = ag.reorder_quantize_w(w.to(DEV), idx, 64)
+        alpha = float(sx * sw) * 40.0                                                   # activations of order 1..10
+        y = ag.matmul(qx, qw, sfx, sfw, alpha)
+        want = F.silu(y[:, 0::2]) * y[:, 1::2]
+        act, slots = ag.matmul_silu_mul(qx, qw, sfx, sfw, alpha)
+        assert act.shape == (M, IT) and torch.equal(act, want), (M, IT, KQ)
+        dev_alpha = torch.tensor(alpha / 0.5, dtype=torch.float32, device=DEV)
+        act2, _ = ag.matmul_silu_mul(qx, qw, sfx, sfw, dev_alpha, scale_host=0.5)
+        assert torch.equal(act2, want)
+        if IT % 16 == 0 and (IT + 64) % 64 == 0:
+            idx2 = random_perm(IT, 8).to(DEV)
+            q1, sf1, s1 = ag.reorder_quantize_x_dynamic(want.contiguous(), idx2, 64)
+            q2, sf2, s2 = ag.reorder_quantize_x_dynamic(act, idx2, 64, absmax_slots=slots)
+            assert s1.item() == s2.item() and torch.equal(q1, q2)
+            used = _used_sf_mask(M, IT + 64, sf1.numel())
+            assert torch.equal(sf1.cpu()[used], sf2.cpu()[used])
+    with pytest.raises(RuntimeError):
+        ag.matmul_silu_mul(qx, qw[:-4], sfx, sfw, 1.0)                                   # N % 8 != 0
+
+
 def test_gemm_epilogue_operands_on_every_kernel():
     """bias + residual + device scale through the 16-row decode kernel, the 32-row decode kernel, the split-K tile
     path and the 256x256 tile: the fused epilogue equals the separate torch ops on the plain result, and doubling
