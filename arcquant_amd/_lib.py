@@ -35,7 +35,7 @@ SYMBOLS = {
     "arcq_gemm_nvfp4": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _f32, _p, _p, _p, _i32, _p, _i64, _p]),
     "arcq_absmax_scale": (_i32, [_p, _i64, _p, _p]),
     "arcq_quantize_x_dyn": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p]),
-    "arcq_silu_mul_quantize_x_dyn": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p]),
+    "arcq_silu_mul_quantize_x_dyn": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _i32, _p]),
     "arcq_gemm_silu_mul_slots": (_i64, [_i64, _i64, _i64]),
     "arcq_gemm_nvfp4_silu_mul": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f32, _p, _p]),
     "arcq_quantize_x_dyn_slots": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _p]),

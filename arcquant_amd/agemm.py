@@ -175,7 +175,7 @@ def absmax_scale(X: torch.Tensor) -> torch.Tensor:
 _dyn_state = {}
 
 
-def _quantize_dynamic(entry: str, who: str, X: torch.Tensor, KQ: int, reorder_index: torch.Tensor, KE: int, variant, slots=None):
+def _quantize_dynamic(entry: str, who: str, X: torch.Tensor, KQ: int, reorder_index: torch.Tensor, KE: int, variant, slots=None, layout=None):
     _need(reorder_index, torch.int16, "reorder_index", 1)
     M = X.shape[0]
     KE = int(KE)
@@ -196,6 +196,9 @@ def _quantize_dynamic(entry: str, who: str, X: torch.Tensor, KQ: int, reorder_in
         if slots is not None:
             st = getattr(_lib.lib(), entry)(X.data_ptr(), reorder_index.data_ptr(), QX.data_ptr(), SFX.data_ptr(), scale.data_ptr(),
                                             slots.data_ptr(), slots.numel(), M, KQ, KE, int(variant), _stream(X))
+        elif layout is not None:
+            st = getattr(_lib.lib(), entry)(X.data_ptr(), reorder_index.data_ptr(), QX.data_ptr(), SFX.data_ptr(), scale.data_ptr(),
+                                            state.data_ptr(), M, KQ, KE, int(variant), int(layout), _stream(X))
         else:
             st = getattr(_lib.lib(), entry)(X.data_ptr(), reorder_index.data_ptr(), QX.data_ptr(), SFX.data_ptr(), scale.data_ptr(),
                                             state.data_ptr(), M, KQ, KE, int(variant), _stream(X))
@@ -244,16 +247,22 @@ def reorder_quantize_x_dynamic(X: torch.Tensor, reorder_index: torch.Tensor, KE:
     return _quantize_dynamic("arcq_quantize_x_dyn", "reorder_quantize_x_dynamic", X, X.shape[1], reorder_index, KE, variant)
 
 
-def silu_mul_quantize_x_dynamic(GU: torch.Tensor, reorder_index: torch.Tensor, KE: int, variant=None):
+GU_HALVES, GU_PAIRS = 0, 1
+
+
+def silu_mul_quantize_x_dynamic(GU: torch.Tensor, reorder_index: torch.Tensor, KE: int, variant=None, layout: int = GU_HALVES):
     """Extension: the MLP's ``act_fn(gate) * up`` (model/qLlamaLayer.py:417, SiLU) folded into the dynamic quantiser.
-    ``GU`` is [M, 2*KQ] bf16 = (gate | up), the output of a fused gate_up projection; returns what
-    ``reorder_quantize_x_dynamic(F.silu(GU[:, :KQ]) * GU[:, KQ:], ...)`` returns, byte for byte, in two launches instead
-    of four and without materialising the product."""
+    ``GU`` is [M, 2*KQ] bf16, the output of a fused gate_up projection: ``layout=GU_HALVES`` (gate | up) or ``GU_PAIRS``
+    (g0, u0, g1, u1, ...: a weight with interleaved gate/up rows, as ``matmul_silu_mul`` takes).  Returns what
+    ``reorder_quantize_x_dynamic(F.silu(gate) * up, ...)`` returns, byte for byte, in two launches instead of four and
+    without materialising the product."""
     _need(GU, torch.bfloat16, "GU", 2)
     if GU.shape[1] % 2:
         raise RuntimeError("Value error in silu_mul_quantize_x_dynamic: GU must hold gate and up halves of equal width")
+    if layout not in (GU_HALVES, GU_PAIRS):
+        raise RuntimeError("Value error in silu_mul_quantize_x_dynamic: layout must be GU_HALVES or GU_PAIRS")
     return _quantize_dynamic("arcq_silu_mul_quantize_x_dyn", "silu_mul_quantize_x_dynamic", GU, GU.shape[1] // 2, reorder_index, KE,
-                             variant)
+                             variant, layout=layout)
 
 
 # --- KV-cache functions of the reference module (bindings.cpp:576-581): OUT OF SCOPE (SURVEY.md row 12).

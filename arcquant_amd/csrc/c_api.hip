@@ -73,8 +73,8 @@ int arcq_quantize_x_dyn(const void* X, const int16_t* reorder_index, uint8_t* QX
 }
 
 int arcq_silu_mul_quantize_x_dyn(const void* GU, const int16_t* reorder_index, uint8_t* QX, uint8_t* SFX, float* scale_out, void* state,
-                                 int64_t M, int64_t KQ, int64_t KE, int variant, void* stream) {
-  return silu_mul_quantize_x_dyn(GU, reorder_index, QX, SFX, scale_out, state, M, KQ, KE, variant, (hipStream_t)stream);
+                                 int64_t M, int64_t KQ, int64_t KE, int variant, int layout, void* stream) {
+  return silu_mul_quantize_x_dyn(GU, reorder_index, QX, SFX, scale_out, state, M, KQ, KE, variant, layout, (hipStream_t)stream);
 }
 
 int arcq_absmax_scale(const void* X, int64_t n, float* scale_out, void* stream) {

@@ -78,8 +78,9 @@ struct DecodeRegs {
   uint32_t sa0, sa1, sa2, sa3;
 };
 
-// kADw = activation dwords per thread and item = ceil(M / 4)
-template <int kADw>
+// kADw = activation dwords per thread and item = ceil(M / 4); kEpi = kEpiPlain | kEpiSiluMul (a template parameter: as
+// a run-time branch the SiLU epilogue's exp code cost the plain kernel 26 spilled registers and 3.5 us on qkv)
+template <int kADw, int kEpi>
 __global__ __launch_bounds__(kDecThreads, kADw == 1 ? 4 : 2) void gemm_decode_kernel(DecodeParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lds_buf = kDecBImg + (p.M + 1) * kDecAStride;
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(kDecThreads, kADw == 1 ? 4 : 2) void gemm_decode_ke
         }
         // rho = 4q + e of block b is row 32q + 8t + 4b + e of the super-tile: 8 consecutive columns per lane
         const int nn = (cur_tile >> 2) * 128 + (cur_tile & 3) * 8 + q * 32;
-        if (p.epi == kEpiSiluMul) {
+        if (kEpi == kEpiSiluMul) {
           // columns nn..nn+7 = four (gate, up) pairs -> four activations of token rl; never split (launcher); N % 8 == 0
           uint32_t mx = 0;
           if (m_ok && nn < p.N) {
@@ -324,11 +325,11 @@ int64_t gemm_decode_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   return s > 1 ? (int64_t)s * M * N * (int64_t)sizeof(float) : 0;
 }
 
-template <int kADw>
+template <int kADw, int kEpi>
 static int launch_decode(const DecodeParams& p, int splitk, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_decode_kernel<kADw>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_decode_kernel<kADw, kEpi>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        decode_lds_bytes(4 * kADw));
     if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_gemm_nvfp4 (decode): cannot reserve LDS: %s", hipGetErrorString(e));
     attr_set = true;
@@ -339,7 +340,7 @@ static int launch_decode(const DecodeParams& p, int splitk, hipStream_t stream) 
   const int max_wg = forced_grid > 0 ? forced_grid : 256 * per_cu;
   const int per_split = max_wg / splitk > 0 ? max_wg / splitk : 1;
   const int gx = p.tiles < per_split ? p.tiles : per_split;
-  hipLaunchKernelGGL(gemm_decode_kernel<kADw>, dim3((unsigned)gx, (unsigned)splitk), dim3(kDecThreads), decode_lds_bytes(p.M), stream, p);
+  hipLaunchKernelGGL((gemm_decode_kernel<kADw, kEpi>), dim3((unsigned)gx, (unsigned)splitk), dim3(kDecThreads), decode_lds_bytes(p.M), stream, p);
   return ARCQ_OK;
 }
 
@@ -371,7 +372,13 @@ int gemm_decode(const GemmArgs& a, hipStream_t stream) {
   }
   if ((int64_t)a.N * (a.K / 2) >= ((int64_t)1 << 32) || (int64_t)((a.N + 127) / 128) * 128 * (a.K / 16) >= ((int64_t)1 << 32))
     return fail(ARCQ_ERR_UNSUPPORTED, "arcq_gemm_nvfp4 (decode): operand larger than 4 GiB");
-  const int rc = a.M <= 4 ? launch_decode<1>(p, splitk, stream) : a.M <= 8 ? launch_decode<2>(p, splitk, stream) : launch_decode<4>(p, splitk, stream);
+  int rc;
+  if (a.epilogue == kEpiSiluMul)
+    rc = a.M <= 4 ? launch_decode<1, kEpiSiluMul>(p, splitk, stream)
+                  : a.M <= 8 ? launch_decode<2, kEpiSiluMul>(p, splitk, stream) : launch_decode<4, kEpiSiluMul>(p, splitk, stream);
+  else
+    rc = a.M <= 4 ? launch_decode<1, kEpiPlain>(p, splitk, stream)
+                  : a.M <= 8 ? launch_decode<2, kEpiPlain>(p, splitk, stream) : launch_decode<4, kEpiPlain>(p, splitk, stream);
   if (rc != ARCQ_OK) return rc;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_gemm_nvfp4 (decode): launch failed: %s", hipGetErrorString(e));

@@ -26,7 +26,7 @@
 
 namespace arcq {
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool kMfma32>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool kMfma32, int kEpi>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TileParams p) {
   constexpr int kThreads = WAVES_M * WAVES_N * 64;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;     // wave tile
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
   uint32_t act_max = 0;                       // kEpiSiluMul: max |act| of this thread, as bf16 magnitude bits
   auto store4 = [&](int m, int n, float d0, float d1, float d2, float d3) {
     if (m >= p.M || n >= p.N) return;
-    if (p.epi == kEpiSiluMul) {               // columns n..n+3 = (gate_j, up_j, gate_j+1, up_j+1), j = n / 2; N % 4 == 0
+    if (kEpi == kEpiSiluMul) {                // columns n..n+3 = (gate_j, up_j, gate_j+1, up_j+1), j = n / 2; N % 4 == 0
       const uint32_t a0 = silu_mul_bf16(f32_to_bf16_bits(alpha * d0), f32_to_bf16_bits(alpha * d1));
       const uint32_t a1 = silu_mul_bf16(f32_to_bf16_bits(alpha * d2), f32_to_bf16_bits(alpha * d3));
       *reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(p.D) + (size_t)m * (p.N >> 1) + (n >> 1)) = a0 | (a1 << 16);
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
       }
     }
   }
-  if (p.epi == kEpiSiluMul) {                 // workgroup-uniform
+  if (kEpi == kEpiSiluMul) {
     __shared__ uint32_t wave_max[WAVES_M * WAVES_N];
 #pragma unroll
     for (int sh = 32; sh > 0; sh >>= 1) act_max = max(act_max, (uint32_t)__shfl_down((int)act_max, sh, 64));
@@ -277,7 +277,7 @@ static void tile_split(int64_t M, int64_t N, int64_t K, int BM, int BN, int* spl
   *atoms_per_split = per;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool kMfma32 = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool kMfma32 = false, int kEpi = kEpiPlain>
 static int launch_tile(const GemmArgs& a, hipStream_t stream, bool allow_split = false) {
   TileParams p;
   p.A = a.A; p.B = a.B; p.SFA = a.SFA; p.SFB = a.SFB; p.D = a.D;
@@ -298,7 +298,7 @@ static int launch_tile(const GemmArgs& a, hipStream_t stream, bool allow_split =
     }
   }
   const size_t lds = 2 * (size_t)(BM + BN) * kRowBytes;
-  auto kern = gemm_tile_kernel<BM, BN, WAVES_M, WAVES_N, kMfma32>;
+  auto kern = gemm_tile_kernel<BM, BN, WAVES_M, WAVES_N, kMfma32, kEpi>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_gemm_nvfp4 (tile): cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
@@ -370,6 +370,15 @@ int64_t gemm_tile_workspace_bytes(int64_t M, int64_t N, int64_t K) {
 }
 
 int gemm_tile(const GemmArgs& a, hipStream_t stream) {
+  if (a.epilogue == kEpiSiluMul) {           // the epilogue is a template parameter: the plain kernels do not carry its exp code
+    switch (effective_tile_kind(a.M, a.N)) {
+      case kTile128: return launch_tile<128, 128, 2, 2, false, kEpiSiluMul>(a, stream);
+      case kTile64: return launch_tile<64, 256, 1, 4, false, kEpiSiluMul>(a, stream);
+      case kTile32: return launch_tile<32, 256, 1, 4, false, kEpiSiluMul>(a, stream);
+      case -4: return launch_tile<128, 256, 2, 2, false, kEpiSiluMul>(a, stream);
+      default: return launch_tile<256, 256, 2, 4, false, kEpiSiluMul>(a, stream);
+    }
+  }
   switch (tile_cfg_override()) {
     case 1: return launch_tile<128, 128, 2, 2>(a, stream, true);
     case 2: return launch_tile<256, 256, 2, 2>(a, stream);

@@ -93,6 +93,32 @@ __device__ __forceinline__ uint4 silu_mul_chunk(const uint4 g, const uint4 u) {
     o[j] = silu_mul_bf16(gw[j] & 0xffffu, uw[j] & 0xffffu) | (silu_mul_bf16(gw[j] >> 16, uw[j] >> 16) << 16);
   return make_uint4(o[0], o[1], o[2], o[3]);
 }
+// eight activations from sixteen interleaved values (g0, u0, g1, u1, ...): every dword is one (gate, up) pair
+__device__ __forceinline__ uint4 silu_mul_pairs(const uint4 lo, const uint4 hi) {
+  const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  uint32_t o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    o[j] = silu_mul_bf16(w[2 * j] & 0xffffu, w[2 * j] >> 16) | (silu_mul_bf16(w[2 * j + 1] & 0xffffu, w[2 * j + 1] >> 16) << 16);
+  return make_uint4(o[0], o[1], o[2], o[3]);
+}
+// chunk c (8 activations) of a row: kSiluHalves: gate at g[8c..], up at u[8c..]; kSiluPairs: pairs at g[16c..]
+enum : int { kSiluNone = 0, kSiluHalves = 1, kSiluPairs = 2 };
+template <int kSilu>
+__device__ __forceinline__ uint4 silu_act_chunk(const uint16_t* g, const uint16_t* u, int64_t c) {
+  if (kSilu == kSiluPairs)
+    return silu_mul_pairs(*reinterpret_cast<const uint4*>(g + c * 16), *reinterpret_cast<const uint4*>(g + c * 16 + 8));
+  return silu_mul_chunk(*reinterpret_cast<const uint4*>(g + c * 8), *reinterpret_cast<const uint4*>(u + c * 8));
+}
+template <int kSilu>
+__device__ __forceinline__ uint32_t silu_act_elem(const uint16_t* g, const uint16_t* u, uint32_t i) {
+  if (kSilu == kSiluPairs) {
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(g + 2 * i);
+    return silu_mul_bf16(w & 0xffffu, w >> 16);
+  }
+  return silu_mul_bf16(g[i], u[i]);
+}
+
 __device__ __forceinline__ uint32_t absmax_bits_chunk(const uint4 d, uint32_t m) {
   const uint32_t w4[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
@@ -131,12 +157,13 @@ __device__ __forceinline__ float rms_sumsq_tree(float* s, int bdx) {
 //              single launch (a launch costs ~4.6 us in a replayed graph, re-reading <= 256 KB from L2 well under 1).
 // Every element is first divided by scale = amax * (1/2688) and rounded to bf16 -- exactly what torch's GPU `x / scale`
 // with a 0-dim fp32 scale computes (model/qLlamaLayer.py:74-76) -- so the separate abs/max/div passes vanish.
-// kSilu: the row is silu(X) * Xup computed on the fly (both with row stride ldx).
+// kSilu: the row is silu(gate) * up computed on the fly from X (gate) and Xup (up), both with row stride ldx
+// (kSiluHalves), or from (gate, up) pairs interleaved in X (kSiluPairs).
 // kDyn / kSilu are template parameters: as run-time branches inside the 16-element gather they cost the static
 // quantiser 18 % (15.7 -> 18.5 us at 4096^2) and the dynamic one most of its time.
 enum : int { kDynNone = 0, kDynState = 1, kDynLocal = 2 };
 
-template <int kVariant, int kMode, int kDyn, bool kSilu>
+template <int kVariant, int kMode, int kDyn, int kSilu>
 __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
     const uint16_t* __restrict__ X, const uint16_t* __restrict__ Xup, int64_t ldx, const uint16_t* __restrict__ Wn, float eps,
     const int16_t* __restrict__ idx, uint8_t* __restrict__ Q, uint8_t* __restrict__ SF, int rows, int KQ, int KE,
@@ -233,8 +260,7 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
       } else if (kSilu) {
         const uint16_t* urow = Xup + (size_t)row * ldx;
         for (int c = tid; c < chunks; c += kQuantThreads)
-          *reinterpret_cast<uint4*>(row_lds + (size_t)c * 8) =
-              silu_mul_chunk(*reinterpret_cast<const uint4*>(xrow + (size_t)c * 8), *reinterpret_cast<const uint4*>(urow + (size_t)c * 8));
+          *reinterpret_cast<uint4*>(row_lds + (size_t)c * 8) = silu_act_chunk<kSilu>(xrow, urow, c);
       } else {
         for (int c = tid; c < chunks; c += kQuantThreads)
           *reinterpret_cast<uint4*>(row_lds + (size_t)c * 8) = *reinterpret_cast<const uint4*>(xrow + (size_t)c * 8);
@@ -255,8 +281,8 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
         float a, b;
         if (kSilu && gridDim.y > 1) {
           const uint16_t* urow = Xup + (size_t)row * ldx;
-          a = bf16_bits_to_f32(silu_mul_bf16(xrow[ia], urow[ia]));
-          b = bf16_bits_to_f32(silu_mul_bf16(xrow[ib], urow[ib]));
+          a = bf16_bits_to_f32(silu_act_elem<kSilu>(xrow, urow, ia));
+          b = bf16_bits_to_f32(silu_act_elem<kSilu>(xrow, urow, ib));
         } else {
           a = bf16_bits_to_f32(row_lds[ia]);
           b = bf16_bits_to_f32(row_lds[ib]);
@@ -350,13 +376,14 @@ __global__ __launch_bounds__(kAbsmaxThreads) void absmax_bits_kernel(const uint1
 }
 
 // slots[blockIdx.x] = max |silu(G) * U| over a [rows, KQ] view of two strided operands (KQ % 8 == 0)
+template <int kSilu>
 __global__ __launch_bounds__(kAbsmaxThreads) void silu_mul_absmax_kernel(const uint16_t* __restrict__ G, const uint16_t* __restrict__ U,
                                                                           int64_t ldx, int rows, int chunks, unsigned int* __restrict__ slots) {
   uint32_t m = 0;
   const int64_t total = (int64_t)rows * chunks;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / chunks, c = i - r * chunks;
-    m = absmax_bits_chunk(silu_mul_chunk(*reinterpret_cast<const uint4*>(G + r * ldx + c * 8), *reinterpret_cast<const uint4*>(U + r * ldx + c * 8)), m);
+    m = absmax_bits_chunk(silu_act_chunk<kSilu>(G + r * ldx, U + r * ldx, c), m);
   }
   m = block_max_bits(m);
   if (threadIdx.x == 0) slots[blockIdx.x] = m;
@@ -374,7 +401,7 @@ __global__ void absmax_finish_kernel(unsigned int* slot, float* scale_out) {
 // ----------------------------------------------------------------------------------------------------
 constexpr int kMaxQuantBlocks = 2048;   // 256 CUs x 8 resident workgroups, rows are grid-strided beyond
 
-template <int kMode, int kDyn = kDynNone, bool kSilu = false>
+template <int kMode, int kDyn = kDynNone, int kSilu = kSiluNone>
 static int launch_quantize(const void* X, const void* Wn, float eps, const int16_t* idx, uint8_t* Q, uint8_t* SF,
                            int64_t rows, int64_t KQ, int64_t KE, int variant, hipStream_t stream, const char* who,
                            const unsigned int* dyn = nullptr, int nslots = 0, float* scale_out = nullptr, const void* Xup = nullptr,
@@ -467,9 +494,11 @@ int quantize_x_dyn_slots(const void* X, const int16_t* idx, uint8_t* QX, uint8_t
 
 // GU = [M, 2*KQ] bf16 (gate | up, the fused gate_up projection's output): quantise silu(gate) * up with its
 // per-tensor dynamic scale.  Two launches (abs-max of the product, quantise), the product is never materialised.
+// layout: ARCQ_GU_HALVES (gate in columns [0, KQ), up in [KQ, 2KQ)) or ARCQ_GU_PAIRS (g0, u0, g1, u1, ...).
 int silu_mul_quantize_x_dyn(const void* GU, const int16_t* idx, uint8_t* QX, uint8_t* SFX, float* scale_out, void* state, int64_t M,
-                            int64_t KQ, int64_t KE, int variant, hipStream_t stream) {
+                            int64_t KQ, int64_t KE, int variant, int layout, hipStream_t stream) {
   const char* who = "arcq_silu_mul_quantize_x_dyn";
+  if (layout != ARCQ_GU_HALVES && layout != ARCQ_GU_PAIRS) return fail(ARCQ_ERR_SHAPE, "%s: unknown layout %d", who, layout);
   if (!scale_out || !state) return fail(ARCQ_ERR_NULL, "%s: NULL scale_out / state", who);
   const int rc = launch_quantize<kModeX>(GU, nullptr, 0.f, idx, QX, SFX, 0, KQ, KE, variant, stream, who);
   if (rc != ARCQ_OK || M <= 0) return rc;
@@ -483,8 +512,12 @@ int silu_mul_quantize_x_dyn(const void* GU, const int16_t* idx, uint8_t* QX, uin
   const int threads = total >= (int64_t)kAbsmaxMaxBlocks * kAbsmaxThreads ? kAbsmaxThreads : 256;
   const int64_t want = (total + threads - 1) / threads;
   const int grid = (int)(want > kAbsmaxMaxBlocks ? kAbsmaxMaxBlocks : want);
-  hipLaunchKernelGGL(silu_mul_absmax_kernel, dim3(grid), dim3(threads), 0, stream, G, U, 2 * KQ, (int)M, (int)chunks, st);
-  return launch_quantize<kModeX, kDynState, true>(G, nullptr, 0.f, idx, QX, SFX, M, KQ, KE, variant, stream, who, st, grid, scale_out, U, 2 * KQ);
+  if (layout == ARCQ_GU_PAIRS) {
+    hipLaunchKernelGGL(silu_mul_absmax_kernel<kSiluPairs>, dim3(grid), dim3(threads), 0, stream, G, G, 2 * KQ, (int)M, (int)chunks, st);
+    return launch_quantize<kModeX, kDynState, kSiluPairs>(G, nullptr, 0.f, idx, QX, SFX, M, KQ, KE, variant, stream, who, st, grid, scale_out, G, 2 * KQ);
+  }
+  hipLaunchKernelGGL(silu_mul_absmax_kernel<kSiluHalves>, dim3(grid), dim3(threads), 0, stream, G, U, 2 * KQ, (int)M, (int)chunks, st);
+  return launch_quantize<kModeX, kDynState, kSiluHalves>(G, nullptr, 0.f, idx, QX, SFX, M, KQ, KE, variant, stream, who, st, grid, scale_out, U, 2 * KQ);
 }
 
 int absmax_scale(const void* X, int64_t n, float* scale_out, hipStream_t stream) {

@@ -125,11 +125,14 @@ int arcq_quantize_x_dyn(const void *X, const int16_t *reorder_index, uint8_t *QX
                         void *state, int64_t M, int64_t KQ, int64_t KE, int variant, void *stream);
 
 /* Extension: the MLP's `act_fn(gate) * up` (model/qLlamaLayer.py:417, SiLU) folded into the dynamic quantiser.
- * GU = [M, 2*KQ] bf16, gate in columns [0, KQ) and up in [KQ, 2*KQ) (the output of a fused gate_up projection);
- * equals arcq_quantize_x_dyn on the bf16 tensor torch computes as silu(gate) * up, which is never materialised.
- * `state` as above. */
+ * GU = [M, 2*KQ] bf16, the output of a fused gate_up projection, in one of two layouts: ARCQ_GU_HALVES = gate in
+ * columns [0, KQ) and up in [KQ, 2*KQ); ARCQ_GU_PAIRS = (g0, u0, g1, u1, ...), the layout of a weight whose gate and
+ * up rows interleave (what arcq_gemm_nvfp4_silu_mul consumes).  Equals arcq_quantize_x_dyn on the bf16 tensor torch
+ * computes as silu(gate) * up, which is never materialised.  `state` as above. */
+#define ARCQ_GU_HALVES 0
+#define ARCQ_GU_PAIRS 1
 int arcq_silu_mul_quantize_x_dyn(const void *GU, const int16_t *reorder_index, uint8_t *QX, uint8_t *SFX, float *scale_out,
-                                 void *state, int64_t M, int64_t KQ, int64_t KE, int variant, void *stream);
+                                 void *state, int64_t M, int64_t KQ, int64_t KE, int variant, int layout, void *stream);
 
 /* ---- f3 extension: the MLP's `act_fn(gate) * up` (SiLU, model/qLlamaLayer.py:417) in the GEMM epilogue -------------
  * B holds the gate and up projections with their ROWS INTERLEAVED (g0, u0, g1, u1, ...: quantise the interleaved

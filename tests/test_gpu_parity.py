@@ -408,8 +408,9 @@ def test_silu_mul_quantizer_equals_torch_pipeline():
         idx = random_perm(KQ, 43).to(DEV)
         act = F.silu(gu[:, :KQ]) * gu[:, KQ:]
         want_q, want_sf, want_scale = ag.reorder_quantize_x_dynamic(act.contiguous(), idx, KE)
-        for _ in range(2):
-            got_q, got_sf, got_scale = ag.silu_mul_quantize_x_dynamic(gu, idx, KE)
+        pairs = torch.stack((gu[:, :KQ], gu[:, KQ:]), dim=2).reshape(M, 2 * KQ).contiguous()      # g0, u0, g1, u1, ...
+        for src, layout in ((gu, ag.GU_HALVES), (pairs, ag.GU_PAIRS), (gu, ag.GU_HALVES)):
+            got_q, got_sf, got_scale = ag.silu_mul_quantize_x_dynamic(src, idx, KE, layout=layout)
             assert got_scale.item() == want_scale.item()
             assert torch.equal(got_q, want_q)
             used = _used_sf_mask(M, KQ + KE, got_sf.numel())
