@@ -314,6 +314,8 @@ static void decode_split(int64_t N, int64_t K, int* splitk, int* slabs_per_split
   if ((N % 4) == 0) {
     while (tiles * s < 192 && nslabs / (s * 2) >= 8 && s < 16) s *= 2;
   }
+  static const int forced = getenv("ARCQ_DECODE_SPLIT") ? atoi(getenv("ARCQ_DECODE_SPLIT")) : 0;   // tuning only
+  if (forced > 0 && (N % 4) == 0) s = forced < nslabs ? forced : nslabs;
   const int per = (nslabs + s - 1) / s;
   *splitk = (nslabs + per - 1) / per;          // drop empty splits
   *slabs_per_split = per;
