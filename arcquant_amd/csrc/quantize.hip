@@ -401,6 +401,16 @@ __global__ void absmax_finish_kernel(unsigned int* slot, float* scale_out) {
 // ----------------------------------------------------------------------------------------------------
 constexpr int kMaxQuantBlocks = 2048;   // 256 CUs x 8 resident workgroups, rows are grid-strided beyond
 
+// grid.x = one workgroup per row (grid-strided beyond kMaxQuantBlocks); few rows (decode): each row is also split
+// over up to 16 workgroups of >= 32 groups so that the chip is not idle
+static void quant_grid(int64_t rows, int64_t KQ, int* grid, int* gsplit) {
+  const int g = (int)(rows < kMaxQuantBlocks ? rows : kMaxQuantBlocks);
+  int s = 1;
+  while (g * s < 256 && s < 16 && (KQ / 16) / (s * 2) >= 32) s *= 2;
+  *grid = g;
+  *gsplit = s;
+}
+
 template <int kMode, int kDyn = kDynNone, int kSilu = kSiluNone>
 static int launch_quantize(const void* X, const void* Wn, float eps, const int16_t* idx, uint8_t* Q, uint8_t* SF,
                            int64_t rows, int64_t KQ, int64_t KE, int variant, hipStream_t stream, const char* who,
@@ -423,10 +433,8 @@ static int launch_quantize(const void* X, const void* Wn, float eps, const int16
   if (rows > INT32_MAX) return fail(ARCQ_ERR_UNSUPPORTED, "%s: too many rows", who);
 
   size_t lds = (size_t)KQ * 2 + (kMode == kModeRms ? 512 * sizeof(float) + (size_t)KQ * 2 : 0);
-  const int grid = (int)(rows < kMaxQuantBlocks ? rows : kMaxQuantBlocks);
-  // few rows (decode): also split each row over up to 16 workgroups of >= 32 groups so that the chip is not idle
-  int gsplit = 1;
-  while (grid * gsplit < 256 && gsplit < 16 && (KQ / 16) / (gsplit * 2) >= 32) gsplit *= 2;
+  int grid, gsplit;
+  quant_grid(rows, KQ, &grid, &gsplit);
   auto go = [&](auto kern) -> int {
     if (lds > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -463,8 +471,11 @@ static int absmax_grid(int64_t chunks) {
   return (int)(want < 1 ? 1 : (want > kAbsmaxMaxBlocks ? kAbsmaxMaxBlocks : want));
 }
 
-// Largest input (bytes) for which every workgroup recomputes max|X| itself instead of a separate abs-max launch
+// Every workgroup recomputes max|X| itself (one launch instead of two) while the input is small (bytes) AND the
+// redundant L2 reads of all workgroups together stay small: 4 x 18944 over 64 workgroups = 9.7 MB is cheaper than a
+// launch (~4.6 us), 64 x 2048 over 256 workgroups = 64 MB is not
 constexpr int64_t kDynLocalMaxBytes = 256 * 1024;
+constexpr int64_t kDynLocalMaxTotalBytes = 16 * 1024 * 1024;
 
 int quantize_x_dyn(const void* X, const int16_t* idx, uint8_t* QX, uint8_t* SFX, float* scale_out, void* state, int64_t M,
                    int64_t KQ, int64_t KE, int variant, hipStream_t stream) {
@@ -477,7 +488,9 @@ int quantize_x_dyn(const void* X, const int16_t* idx, uint8_t* QX, uint8_t* SFX,
   if ((reinterpret_cast<uintptr_t>(X) & 15) != 0) return fail(ARCQ_ERR_SHAPE, "arcq_quantize_x_dyn: X must be 16-byte aligned");
   unsigned int* st = reinterpret_cast<unsigned int*>(state);     // ARCQ_DYN_STATE_BYTES of scratch, fully rewritten here
   const int64_t n = M * KQ, n8 = n / 8;
-  if (n * 2 <= kDynLocalMaxBytes)     // decode-sized: one launch, `state` untouched
+  int qg, qs;
+  quant_grid(M, KQ, &qg, &qs);
+  if (n * 2 <= kDynLocalMaxBytes && n * 2 * qg * qs <= kDynLocalMaxTotalBytes)     // decode-sized: one launch, `state` untouched
     return launch_quantize<kModeX, kDynLocal>(X, nullptr, 0.f, idx, QX, SFX, M, KQ, KE, variant, stream, "arcq_quantize_x_dyn", nullptr, 0, scale_out);
   const int grid = absmax_grid(n8);
   hipLaunchKernelGGL(absmax_bits_kernel<false>, dim3(grid), dim3(kAbsmaxThreads), 0, stream, (const uint16_t*)X, n8, n, st);

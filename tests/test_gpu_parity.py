@@ -365,7 +365,7 @@ def test_dynamic_quantizer_equals_torch_prescale_pipeline():
     scale = max|x|/2688; x/scale in torch; reorder_quantize_x) byte for byte, for decode- and prefill-sized inputs,
     and repeated calls keep working (the abs-max scratch is rewritten by every call)."""
     ag = _agemm()
-    for (M, KQ, KE) in [(4, 3584, 64), (1, 4096, 64), (300, 2048, 128), (4, 18944, 64)]:
+    for (M, KQ, KE) in [(4, 3584, 64), (1, 4096, 64), (300, 2048, 128), (4, 18944, 64), (64, 2048, 64), (16, 4096, 64)]:
         x = outlier_activations(M, KQ, 40 + M).to(DEV)
         idx = random_perm(KQ, 41).to(DEV)
         for _ in range(2):
