@@ -26,7 +26,11 @@
 //   * packed bytes are transposed into the MFMA operand layout through a double-buffered LDS image
 //     (padded rows: conflict-free), one barrier per item; cross-wave reduction through LDS per tile;
 //     fused epilogue; split-K over slabs (second pass) only when the tiles alone cannot fill the chip.
+//   * scale pairs are prepared with two instructions (v_bfe_u32 + one 24-bit multiply), row-bound masks once per tile:
+//     184 instructions per item-step (32 B of weights per thread) against 246 per 32 B in the first generation.
 // Used from N = 5120 up (c_api.hip); below that a workgroup lives for 2-5 items and gemm_skinny.hip is faster.
+// Measured (tools/decode_bench.py, M=4, HIP-graph replay): N=37888 K=3648 28.7 -> 22.6 us (3.46 TB/s), N=14336 K=4160
+// 16.0 -> 13.5 us.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
