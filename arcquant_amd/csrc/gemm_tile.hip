@@ -26,7 +26,12 @@
 
 namespace arcq {
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool kMfma32, int kEpi>
+// kStagger (8-wave tiles): the two waves of a SIMD (w and w + 4) run half a step apart -- waves 0-3 multiply step k and
+// then stage step k+1, waves 4-7 stage step k+2 FIRST (into the buffer step k was just read from, after the barrier)
+// and then multiply step k+1 -- so that one wave's dequantise/ds_write phase overlaps the other's MFMA phase instead
+// of both waves of a SIMD leaving the matrix pipe idle together.  ONE loop body with a barrier on either side of the
+// staging block, each taken by one group (every wave still meets one barrier per step): no code is duplicated.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool kMfma32, int kEpi, bool kStagger, bool kPipe>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TileParams p) {
   constexpr int kThreads = WAVES_M * WAVES_N * 64;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;     // wave tile
@@ -161,20 +166,91 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
   // One K step, branch-free: multiply the tile in (ca, cb) while the registers of the next step are
   // dequantised into (na, nb) and the loads of the step after that are issued.  The K index is clamped,
   // so the last steps re-stage the final atom into a buffer nobody reads.
-  auto k_step = [&](int kt, const unsigned char* ca, const unsigned char* cb, unsigned char* na, unsigned char* nb) {
+  const bool late = kStagger && wave >= 4;       // wave-uniform: this wave stages one step further ahead, after the barrier
+  auto k_step = [&](int kt, unsigned char* ca, unsigned char* cb, unsigned char* na, unsigned char* nb) {
+    Staged ta[A_UNITS], tb[B_UNITS];
+#pragma unroll
+    for (int u = 0; u < A_UNITS; ++u) ta[u] = sa[u];
+#pragma unroll
+    for (int u = 0; u < B_UNITS; ++u) tb[u] = sb[u];
+    load_step(min(kt + 2 + (late ? 1 : 0), a_end - 1));   // in flight during this whole step
+    __builtin_amdgcn_sched_barrier(0);            // keep the loads at the top: hipcc otherwise sinks them to the barrier
+    mma_step(ca, cb);
+    if (kStagger && late) __syncthreads();        // every wave has multiplied step kt: its buffer may be overwritten
+    unsigned char* const wa = late ? ca : na;
+    unsigned char* const wb = late ? cb : nb;
+#pragma unroll
+    for (int u = 0; u < A_UNITS; ++u)
+      if (!A_PARTIAL || tid < BM * 2) stage_store(wa, a_slot[u], ta[u], a_live[u]);
+#pragma unroll
+    for (int u = 0; u < B_UNITS; ++u) stage_store(wb, b_slot[u], tb[u], b_live[u]);
+    if (!kStagger || !late) __syncthreads();
+  };
+
+  // Hand-pipelined K step (16x16x32 MFMA): the compiler's own schedule waits for every pair of fragment reads right
+  // after issuing it (LDS latency exposed every 8 MFMAs) and clusters the dequantisation.  Here a step is cut into
+  // TM blocks of [2 fragment reads for the NEXT block | 2 x TN MFMAs of this block | 1/TM of the staging work], fenced
+  // with sched_barrier so that hipcc keeps the order; waits become counted lgkmcnt(N) on reads issued a block earlier.
+  auto k_step_pipe = [&](int kt, unsigned char* ca, unsigned char* cb, unsigned char* na, unsigned char* nb) {
+    static_assert(kMfma32 || TM % 2 == 0, "pairs of A fragments");
     Staged ta[A_UNITS], tb[B_UNITS];
 #pragma unroll
     for (int u = 0; u < A_UNITS; ++u) ta[u] = sa[u];
 #pragma unroll
     for (int u = 0; u < B_UNITS; ++u) tb[u] = sb[u];
     load_step(min(kt + 2, a_end - 1));            // in flight during this whole step
-    __builtin_amdgcn_sched_barrier(0);            // keep the loads at the top: hipcc otherwise sinks them to the barrier
-    mma_step(ca, cb);
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int kPieces = (A_UNITS + B_UNITS) * 4, kBlocks = TM;     // 2 K halves x TM/2 fragment pairs
+    auto rd_a = [&](int ks, int i) { Frag8 f; f.u = *reinterpret_cast<const uint4*>(ca + (fa_base ^ (ks * 64)) + i * 16 * kRowBytes); return f; };
+    auto rd_b = [&](int ks, int j) { Frag8 f; f.u = *reinterpret_cast<const uint4*>(cb + (fb_base ^ (ks * 64)) + j * 16 * kRowBytes); return f; };
+    Frag8 fb[TN], fa[2], fbn[TN], fan[2];
 #pragma unroll
-    for (int u = 0; u < A_UNITS; ++u)
-      if (!A_PARTIAL || tid < BM * 2) stage_store(na, a_slot[u], ta[u], a_live[u]);
+    for (int j = 0; j < TN; ++j) fb[j] = rd_b(0, j);
+    fa[0] = rd_a(0, 0);
+    fa[1] = rd_a(0, 1);
 #pragma unroll
-    for (int u = 0; u < B_UNITS; ++u) stage_store(nb, b_slot[u], tb[u], b_live[u]);
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int pr = 0; pr < TM / 2; ++pr) {
+        const int blk = ks * (TM / 2) + pr;
+        // (1) reads for the next block
+        if (pr + 1 < TM / 2) {
+          fan[0] = rd_a(ks, 2 * pr + 2);
+          fan[1] = rd_a(ks, 2 * pr + 3);
+        } else if (ks == 0) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fbn[j] = rd_b(1, j);
+          fan[0] = rd_a(1, 0);
+          fan[1] = rd_a(1, 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // (2) this block's MFMAs; weights are the MFMA A operand
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            if constexpr (!kMfma32)
+              acc[2 * pr + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j].v, fa[ii].v, acc[2 * pr + ii][j], 0, 0, 0);
+        // (3) its share of the staging of step kt + 1
+#pragma unroll
+        for (int c = blk; c < kPieces; c += kBlocks) {
+          const int u = c >> 2, j = c & 3;
+          if (u < A_UNITS) {
+            if (!A_PARTIAL || tid < BM * 2) stage_piece(na, a_slot[u < A_UNITS ? u : 0][j], ta[u < A_UNITS ? u : 0], a_live[u < A_UNITS ? u : 0], j);
+          } else {
+            const int v = u - A_UNITS < B_UNITS ? u - A_UNITS : 0;
+            stage_piece(nb, b_slot[v][j], tb[v], b_live[v], j);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        fa[0] = fan[0];
+        fa[1] = fan[1];
+        if (pr + 1 == TM / 2 && ks == 0) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[j] = fbn[j];
+        }
+      }
+    }
     __syncthreads();
   };
 
@@ -182,13 +258,25 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
   load_step(a_begin);
   store_step(lds_a0, lds_b0);
   load_step(min(a_begin + 1, a_end - 1));
+  if (kStagger && late) {                       // the late group enters the loop with step 1 staged and step 2 in registers
+    store_step(lds_a1, lds_b1);
+    load_step(min(a_begin + 2, a_end - 1));
+  }
   __syncthreads();
   int kt = a_begin;
-  for (; kt + 1 < a_end; kt += 2) {
-    k_step(kt, lds_a0, lds_b0, lds_a1, lds_b1);
-    k_step(kt + 1, lds_a1, lds_b1, lds_a0, lds_b0);
+  if constexpr (kPipe) {
+    for (; kt + 1 < a_end; kt += 2) {
+      k_step_pipe(kt, lds_a0, lds_b0, lds_a1, lds_b1);
+      k_step_pipe(kt + 1, lds_a1, lds_b1, lds_a0, lds_b0);
+    }
+    if (kt < a_end) k_step_pipe(kt, lds_a0, lds_b0, lds_a1, lds_b1);
+  } else {
+    for (; kt + 1 < a_end; kt += 2) {
+      k_step(kt, lds_a0, lds_b0, lds_a1, lds_b1);
+      k_step(kt + 1, lds_a1, lds_b1, lds_a0, lds_b0);
+    }
+    if (kt < a_end) k_step(kt, lds_a0, lds_b0, lds_a1, lds_b1);
   }
-  if (kt < a_end) k_step(kt, lds_a0, lds_b0, lds_a1, lds_b1);
 
   // ---- epilogue.  16x16 tiles: lane holds D[m = +(lane & 15)][n = +4*(lane >> 4) + r], r = 0..3.
   //      32x32 tiles: lane holds D[m = +(lane & 31)][n = +8*g + 4*(lane >> 5) + r], g = 0..3, r = 0..3.
@@ -277,6 +365,15 @@ static void tile_split(int64_t M, int64_t N, int64_t K, int BM, int BN, int* spl
   *atoms_per_split = per;
 }
 
+static bool tile_stagger() {                    // ARCQ_TILE_STAGGER=0|1 (tuning)
+  static const int v = getenv("ARCQ_TILE_STAGGER") ? atoi(getenv("ARCQ_TILE_STAGGER")) : 0;
+  return v != 0;
+}
+static bool tile_pipe() {                       // ARCQ_TILE_PIPE=0|1 (tuning)
+  static const int v = getenv("ARCQ_TILE_PIPE") ? atoi(getenv("ARCQ_TILE_PIPE")) : 1;
+  return v != 0;
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool kMfma32 = false, int kEpi = kEpiPlain>
 static int launch_tile(const GemmArgs& a, hipStream_t stream, bool allow_split = false) {
   TileParams p;
@@ -298,7 +395,10 @@ static int launch_tile(const GemmArgs& a, hipStream_t stream, bool allow_split =
     }
   }
   const size_t lds = 2 * (size_t)(BM + BN) * kRowBytes;
-  auto kern = gemm_tile_kernel<BM, BN, WAVES_M, WAVES_N, kMfma32, kEpi>;
+  constexpr bool kCanStagger = WAVES_M * WAVES_N == 8, kCanPipe = !kMfma32;
+  auto kern = gemm_tile_kernel<BM, BN, WAVES_M, WAVES_N, kMfma32, kEpi, false, false>;
+  if (kCanPipe && tile_pipe()) kern = gemm_tile_kernel<BM, BN, WAVES_M, WAVES_N, kMfma32, kEpi, false, kCanPipe>;
+  else if (kCanStagger && tile_stagger()) kern = gemm_tile_kernel<BM, BN, WAVES_M, WAVES_N, kMfma32, kEpi, kCanStagger, false>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_gemm_nvfp4 (tile): cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));

@@ -61,6 +61,14 @@ __device__ __forceinline__ Staged stage_load(const uint8_t* __restrict__ qrow, c
   return s;
 }
 
+// One quarter (8 elements, one 16-byte slot) of a staging unit: lets the K loop spread the dequantisation between its
+// MFMA groups.
+__device__ __forceinline__ void stage_piece(unsigned char* tile, int slot, const Staged& s, uint32_t live_mask, int j) {
+  const uint32_t w = j == 0 ? s.q.x : j == 1 ? s.q.y : j == 2 ? s.q.z : s.q.w;
+  const Frag8 f = dequant8(w, sf_pair_at(s.sf & live_mask, j < 2 ? 0 : 8));
+  *reinterpret_cast<uint4*>(tile + slot) = f.u;
+}
+
 __device__ __forceinline__ void stage_store(unsigned char* tile, const int (&slot)[4], const Staged& s, uint32_t live_mask) {
   const uint32_t sf = s.sf & live_mask;
   const f16x2 s0 = sf_pair_at(sf, 0), s1 = sf_pair_at(sf, 8);
