@@ -200,56 +200,79 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
     for (int u = 0; u < B_UNITS; ++u) tb[u] = sb[u];
     load_step(min(kt + 2, a_end - 1));            // in flight during this whole step
     __builtin_amdgcn_sched_barrier(0);
-    constexpr int kPieces = (A_UNITS + B_UNITS) * 4, kBlocks = TM;     // 2 K halves x TM/2 fragment pairs
-    auto rd_a = [&](int ks, int i) { Frag8 f; f.u = *reinterpret_cast<const uint4*>(ca + (fa_base ^ (ks * 64)) + i * 16 * kRowBytes); return f; };
-    auto rd_b = [&](int ks, int j) { Frag8 f; f.u = *reinterpret_cast<const uint4*>(cb + (fb_base ^ (ks * 64)) + j * 16 * kRowBytes); return f; };
-    Frag8 fb[TN], fa[2], fbn[TN], fan[2];
+    constexpr int kPieces = (A_UNITS + B_UNITS) * 4, kBlocks = kMfma32 ? 4 : TM;   // 32x32x16: one block per 16-wide K slice
+    auto pieces = [&](int blk) {                  // this block's share of the staging of step kt + 1
 #pragma unroll
-    for (int j = 0; j < TN; ++j) fb[j] = rd_b(0, j);
-    fa[0] = rd_a(0, 0);
-    fa[1] = rd_a(0, 1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int pr = 0; pr < TM / 2; ++pr) {
-        const int blk = ks * (TM / 2) + pr;
-        // (1) reads for the next block
-        if (pr + 1 < TM / 2) {
-          fan[0] = rd_a(ks, 2 * pr + 2);
-          fan[1] = rd_a(ks, 2 * pr + 3);
-        } else if (ks == 0) {
-#pragma unroll
-          for (int j = 0; j < TN; ++j) fbn[j] = rd_b(1, j);
-          fan[0] = rd_a(1, 0);
-          fan[1] = rd_a(1, 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // (2) this block's MFMAs; weights are the MFMA A operand
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            if constexpr (!kMfma32)
-              acc[2 * pr + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j].v, fa[ii].v, acc[2 * pr + ii][j], 0, 0, 0);
-        // (3) its share of the staging of step kt + 1
-#pragma unroll
-        for (int c = blk; c < kPieces; c += kBlocks) {
-          const int u = c >> 2, j = c & 3;
-          if (u < A_UNITS) {
-            if (!A_PARTIAL || tid < BM * 2) stage_piece(na, a_slot[u < A_UNITS ? u : 0][j], ta[u < A_UNITS ? u : 0], a_live[u < A_UNITS ? u : 0], j);
-          } else {
-            const int v = u - A_UNITS < B_UNITS ? u - A_UNITS : 0;
-            stage_piece(nb, b_slot[v][j], tb[v], b_live[v], j);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        fa[0] = fan[0];
-        fa[1] = fan[1];
-        if (pr + 1 == TM / 2 && ks == 0) {
-#pragma unroll
-          for (int j = 0; j < TN; ++j) fb[j] = fbn[j];
+      for (int c = blk; c < kPieces; c += kBlocks) {
+        const int u = c >> 2, j = c & 3;
+        if (u < A_UNITS) {
+          if (!A_PARTIAL || tid < BM * 2) stage_piece(na, a_slot[u < A_UNITS ? u : 0][j], ta[u < A_UNITS ? u : 0], a_live[u < A_UNITS ? u : 0], j);
+        } else {
+          const int v = u - A_UNITS < B_UNITS ? u - A_UNITS : 0;
+          stage_piece(nb, b_slot[v][j], tb[v], b_live[v], j);
         }
       }
+    };
+    if constexpr (kMfma32) {
+      // 32x32x16 MFMAs last 32 cycles: ~3 VALU instructions fit into each one's shadow.  Blocks = the four 16-wide K
+      // slices; all TM + TN fragments of slice ks + 1 are requested before the TM x TN MFMAs of slice ks.
+      Frag8 f32a[2][TM], f32b[2][TN];
+      auto rd_set = [&](int buf, int ks) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) f32a[buf][i].u = *reinterpret_cast<const uint4*>(ca + (fa_base ^ (ks * 32)) + i * 32 * kRowBytes);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) f32b[buf][j].u = *reinterpret_cast<const uint4*>(cb + (fb_base ^ (ks * 32)) + j * 32 * kRowBytes);
+      };
+      rd_set(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks + 1 < 4) rd_set((ks + 1) & 1, ks + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            if constexpr (kMfma32)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f32b[ks & 1][j].v, f32a[ks & 1][i].v, acc[i][j], 0, 0, 0);
+        pieces(ks);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+      return;
+    }
+    auto rd_a = [&](int ks, int i) { Frag8 f; f.u = *reinterpret_cast<const uint4*>(ca + (fa_base ^ (ks * 64)) + i * 16 * kRowBytes); return f; };
+    auto rd_b = [&](int ks, int j) { Frag8 f; f.u = *reinterpret_cast<const uint4*>(cb + (fb_base ^ (ks * 64)) + j * 16 * kRowBytes); return f; };
+    // fragment queue: A fragments are requested kAhead pairs before their MFMAs, the B set of the second K half during the
+    // last pairs of the first
+    constexpr int kPairs = TM / 2, kSeq = 2 * kPairs, kAhead = 1;   // 2 measured the same (1188-1202 vs 1193-1200) with 8 more registers
+    Frag8 fb[2][TN], fq[kSeq][2];
+    auto rd_pair = [&](int q) {                   // q = ks * kPairs + pr (compile-time after unrolling)
+      fq[q][0] = rd_a(q / kPairs, 2 * (q % kPairs));
+      fq[q][1] = rd_a(q / kPairs, 2 * (q % kPairs) + 1);
+    };
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[0][j] = rd_b(0, j);
+#pragma unroll
+    for (int q = 0; q < kAhead; ++q) rd_pair(q);
+#pragma unroll
+    for (int q = 0; q < kSeq; ++q) {
+      const int ks = q / kPairs, pr = q % kPairs;
+      // (1) reads for later blocks
+      if (q + kAhead < kSeq) rd_pair(q + kAhead);
+      if (ks == 0 && pr == kPairs - 1 - (kAhead - 1 < kPairs - 1 ? kAhead - 1 : kPairs - 1)) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[1][j] = rd_b(1, j);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // (2) this block's MFMAs; weights are the MFMA A operand
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          if constexpr (!kMfma32)
+            acc[2 * pr + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[ks][j].v, fq[q][ii].v, acc[2 * pr + ii][j], 0, 0, 0);
+      pieces(q);                                  // (3) its share of the staging of step kt + 1
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   };
@@ -264,6 +287,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
   }
   __syncthreads();
   int kt = a_begin;
+  // the second-dispatched half of an 8-wave workgroup loses every issue arbitration against its SIMD partner at equal
+  // priority; a static priority for it (never flipped) measured +0.8 % (1192-1203 -> 1209-1212 TFLOP/s)
+  if (WAVES_M * WAVES_N == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
   if constexpr (kPipe) {
     for (; kt + 1 < a_end; kt += 2) {
       k_step_pipe(kt, lds_a0, lds_b0, lds_a1, lds_b1);
@@ -395,7 +421,7 @@ static int launch_tile(const GemmArgs& a, hipStream_t stream, bool allow_split =
     }
   }
   const size_t lds = 2 * (size_t)(BM + BN) * kRowBytes;
-  constexpr bool kCanStagger = WAVES_M * WAVES_N == 8, kCanPipe = !kMfma32;
+  constexpr bool kCanStagger = WAVES_M * WAVES_N == 8, kCanPipe = true;
   auto kern = gemm_tile_kernel<BM, BN, WAVES_M, WAVES_N, kMfma32, kEpi, false, false>;
   if (kCanPipe && tile_pipe()) kern = gemm_tile_kernel<BM, BN, WAVES_M, WAVES_N, kMfma32, kEpi, false, kCanPipe>;
   else if (kCanStagger && tile_stagger()) kern = gemm_tile_kernel<BM, BN, WAVES_M, WAVES_N, kMfma32, kEpi, kCanStagger, false>;
