@@ -272,6 +272,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
           if constexpr (!kMfma32)
             acc[2 * pr + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[ks][j].v, fq[q][ii].v, acc[2 * pr + ii][j], 0, 0, 0);
       pieces(q);                                  // (3) its share of the staging of step kt + 1
+      // spacing inside the block: two vector instructions in the shadow of every MFMA (measured on 4096^2, TFLOP/s:
+      // compiler's own placement 1211-1219, 1 MFMA + 1 VALU 1195-1201, 1+2 1234-1236, 1+3 1217-1220, 2+4 1227, 4+5 1180)
+      // The smaller tiles measure the same or slightly worse with it (M=1024: 612 vs 624), so only the 8-fragment tile.
+#pragma unroll
+      for (int m8 = 0; m8 < (TM == 8 ? 2 * TN : 0); ++m8) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
