@@ -514,3 +514,39 @@ def test_gemm_tiny_output_shapes(M, N):
                     torch.from_numpy(sfw).to(DEV), alpha, out_dtype=torch.float32).cpu().numpy()
     assert got.shape == (M, N)
     assert np.all(np.abs(got - want) <= 2e-6 * wabs + 1e-30)
+
+
+def test_gemm_fuzz_random_shapes_against_fp64_matmul():
+    """Sixty seeded random shapes across every dispatch boundary (16-row / 32-row decode kernels, 32- / 64- / 128- / 256-row
+    tiles, split-K on and off, ragged M and N, N % 4 != 0, KE in {0, 64, KQ}) with random e2m1 codes and random ue4m3
+    scale bytes straight in the operand buffers, against an fp64 matmul of the dequantised operands (torch, on the GPU)."""
+    ag = _agemm()
+    rng = np.random.default_rng(20261004)
+    m_pool = [1, 2, 3, 4, 5, 8, 9, 15, 16, 17, 18, 31, 32, 33, 47, 64, 65, 100, 128, 129, 200, 257, 300, 513, 700]
+    n_pool = [1, 7, 16, 24, 100, 127, 128, 129, 255, 256, 384, 500, 1000, 1024, 2050, 4096, 5119, 5120, 5124, 6148]
+    k_pool = [64, 128, 192, 320, 512, 1088, 2048, 3136]
+    for case in range(60):
+        M, N, K = int(rng.choice(m_pool)), int(rng.choice(n_pool)), int(rng.choice(k_pool))
+        if M * N * K > 6e9:
+            K = 320
+        g = torch.Generator(device=DEV).manual_seed(1000 + case)
+
+        def operand(rows):
+            q = torch.randint(0, 256, (rows, K // 2), generator=g, device=DEV, dtype=torch.uint8)
+            nbytes = ag.sf_buffer_bytes(rows, K)
+            # scale bytes: any finite ue4m3 code from the subnormals up to 2^3 (keeps |products| far below fp32 overflow)
+            sf = torch.randint(1, 0x58, (nbytes,), generator=g, device=DEV, dtype=torch.uint8)
+            return q, sf
+
+        A, SFA = operand(M)
+        B, SFB = operand(N)
+        alpha = float(rng.uniform(0.25, 4.0))
+        a64, b64 = _torch_dequant(A, SFA, K), _torch_dequant(B, SFB, K)
+        want = alpha * (a64 @ b64.t())
+        wabs = abs(alpha) * (a64.abs() @ b64.abs().t())
+        got = ag.matmul(A, B, SFA, SFB, alpha, out_dtype=torch.float32).double()
+        assert got.shape == (M, N)
+        err = (got - want).abs()
+        assert bool((err <= 2e-6 * wabs + 1e-30).all()), (case, M, N, K, float((err / (wabs + 1e-30)).max()))
+        got16 = ag.matmul(A, B, SFA, SFB, alpha).double()
+        assert bool(((got16 - want).abs() <= want.abs() * 2.0 ** -8 + 2e-6 * wabs + 1e-30).all()), (case, M, N, K)
