@@ -79,6 +79,33 @@ def test_quantizers_byte_exact(rows, KQ, KE, variant, kind):
     assert np.array_equal(got_sf, want_sf), f"scale bytes differ in {(got_sf != want_sf).sum()} places"
 
 
+def test_quantizer_fuzz_byte_exact():
+    """Forty seeded random (rows, KQ, KE, layout, kind) cases with RAW random bf16 bit patterns (all exponents, both
+    zeros, subnormals; NaN / inf excluded) and random permutations: packed bytes and the whole scale buffer, untouched
+    padding included, equal the kernel-text oracle."""
+    rng = np.random.default_rng(4242)
+    for case in range(40):
+        variant = int(rng.integers(0, 2))
+        unit = 32 if variant == O.G32 else 16
+        KQ = int(rng.choice([64, 128, 192, 256, 448, 1024, 1536, 2048, 3584, 4096, 5120]))
+        ke_opts = [k for k in range(0, KQ + 1, 64) if (KQ + k) % 64 == 0 and k % unit == 0 and KQ % unit == 0]
+        if not ke_opts:
+            continue
+        KE = int(rng.choice(ke_opts[: max(1, min(len(ke_opts), 6))] + [ke_opts[-1]]))
+        rows = int(rng.choice([1, 2, 3, 5, 16, 33, 127, 128, 129, 260]))
+        kind = "x" if rng.integers(0, 2) else "w"
+        xb = rng.integers(0, 1 << 16, size=(rows, KQ), dtype=np.uint16)
+        if case % 2:                       # half of the cases: moderate magnitudes, so that codes other than 0 / +-6 dominate
+            xb = (xb & 0x807F) | (rng.integers(120, 134, size=xb.shape, dtype=np.uint16) << 7)
+        expo = (xb >> 7) & 0xFF
+        xb = np.where(expo == 0xFF, xb & 0x807F, xb).astype(np.uint16)      # inf / nan -> subnormal / zero
+        idx = rng.permutation(KQ).astype(np.int16)
+        want_q, want_sf = (O.quantize_x if kind == "x" else O.quantize_w)(xb, idx, KE, variant, sf_fill=0xEE)
+        got_q, got_sf = _raw_quantize(kind, xb, idx, KE, variant)
+        assert np.array_equal(got_q, want_q), (case, rows, KQ, KE, variant, kind, int((got_q != want_q).sum()))
+        assert np.array_equal(got_sf, want_sf), (case, rows, KQ, KE, variant, kind, int((got_sf != want_sf).sum()))
+
+
 def test_quantizer_special_values_byte_exact():
     """zeros, negative zeros, tiny values (scale floor 2^-9), exact e2m1 ties, saturation at 448*6."""
     KQ = 256
