@@ -471,10 +471,11 @@ static int absmax_grid(int64_t chunks) {
   return (int)(want < 1 ? 1 : (want > kAbsmaxMaxBlocks ? kAbsmaxMaxBlocks : want));
 }
 
-// Every workgroup recomputes max|X| itself (one launch instead of two) while the input is small (bytes) AND the
-// redundant L2 reads of all workgroups together stay small: 4 x 18944 over 64 workgroups = 9.7 MB is cheaper than a
-// launch (~4.6 us), 64 x 2048 over 256 workgroups = 64 MB is not
-constexpr int64_t kDynLocalMaxBytes = 256 * 1024;
+// Every workgroup recomputes max|X| itself (one launch instead of two) while that costs less than the launch it
+// saves.  Measured in a replayed graph (tools/decode_quant_bench.py): a dependent tiny kernel costs ~1.7 us plus its own
+// latency chain; the in-kernel pass over 28 KB (4 x 3584) adds 2.2 us (5.5 against 3.3 us static), over 151 KB
+// (4 x 18944) 7.5 us -- more than an abs-max launch (~3 us).  Also bounded by the total redundant L2 traffic.
+constexpr int64_t kDynLocalMaxBytes = 48 * 1024;
 constexpr int64_t kDynLocalMaxTotalBytes = 16 * 1024 * 1024;
 
 int quantize_x_dyn(const void* X, const int16_t* idx, uint8_t* QX, uint8_t* SFX, float* scale_out, void* state, int64_t M,
