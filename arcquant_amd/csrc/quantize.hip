@@ -154,7 +154,7 @@ __device__ __forceinline__ float rms_sumsq_tree(float* s, int bdx) {
 //              4096 same-address atomics, or a completion ticket taken by 2048 workgroups, serialise on the fabric and
 //              cost 50-100 us -- measured -- where the data pass itself takes 15);
 //   kDynLocal: every workgroup computes max|X| of the WHOLE (small) tensor itself -- decode-sized inputs then need a
-//              single launch (a launch costs ~4.6 us in a replayed graph, re-reading <= 256 KB from L2 well under 1).
+//              single launch (see kDynLocalMaxBytes for where that pays).
 // Every element is first divided by scale = amax * (1/2688) and rounded to bf16 -- exactly what torch's GPU `x / scale`
 // with a 0-dim fp32 scale computes (model/qLlamaLayer.py:74-76) -- so the separate abs/max/div passes vanish.
 // kSilu: the row is silu(gate) * up computed on the fly from X (gate) and Xup (up), both with row stride ldx
