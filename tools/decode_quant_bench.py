@@ -40,3 +40,13 @@ print("reorder_quantize_x   M=4 KQ=3584 : %.2f us" % graph_time(lambda: agemm.re
 print("quantize_x_dynamic   M=4 KQ=3584 : %.2f us" % graph_time(lambda: agemm.reorder_quantize_x_dynamic(x, ih, 64)))
 print("quantize_x_dynamic   M=4 KQ=18944: %.2f us" % graph_time(lambda: agemm.reorder_quantize_x_dynamic(act, ii, 64)))
 print("silu_mul_quantize    M=4 KQ=18944: %.2f us (two launches)" % graph_time(lambda: agemm.silu_mul_quantize_x_dynamic(gu, ii, 64)))
+
+# instruction-cache effect: the same four kernels interleaved (every launch follows a different kernel) against the sum of their times alone
+fns = [lambda: agemm.rmsnorm_quantize_x(x, wn, 1e-6, ih, 64), lambda: agemm.reorder_quantize_x(xs, ih, 64),
+       lambda: agemm.reorder_quantize_x_dynamic(x, ih, 64), lambda: agemm.reorder_quantize_x_dynamic(act, ii, 64)]
+alone = [graph_time(f) for f in fns]
+def mixed():
+    for f in fns:
+        f()
+tm = graph_time(mixed, n=4)
+print("alone: %s  sum %.2f us;  interleaved round of the four: %.2f us" % (["%.2f" % t for t in alone], sum(alone[:3]) + alone[3], tm))
