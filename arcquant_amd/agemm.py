@@ -206,6 +206,87 @@ def _quantize_dynamic(entry: str, who: str, X: torch.Tensor, KQ: int, reorder_in
     return QX, SFX, scale.reshape(())
 
 
+def repack_w(QW: torch.Tensor, SFW: torch.Tensor):
+    """One-time re-layout of a quantised weight for the decode fast path (include/arcq.h, "REPACKED weight"): returns
+    ``(RW, RSF)``.  Pure data movement with torch ops -- codes and scale bytes are those of ``reorder_quantize_w``:
+    RW  = [row blocks of 16][tiles of 128 K][lane = 16*q + r][16 bytes], K padded to a multiple of 256, N to 16;
+    RSF = [row blocks][tile pairs][lane][4 bytes: the lane's two scale bytes in each tile of the pair]."""
+    _need(QW, torch.uint8, "QW", 2)
+    _need(SFW, torch.uint8, "SFW", 1)
+    N, K = QW.shape[0], QW.shape[1] * 2
+    if K % 64 or SFW.numel() < _lib.lib().arcq_sf_used_bytes(N, K):
+        raise RuntimeError("Value error in repack_w: K % 64 != 0 or the scale buffer is too small")
+    dev = QW.device
+    Np, Kp = (N + 15) // 16 * 16, (K + 255) // 256 * 256
+    q = torch.zeros((Np, Kp // 2), dtype=torch.uint8, device=dev)
+    q[:N, : K // 2] = QW
+    # natural [N, K/16] scale matrix out of the swizzled buffer
+    r = torch.arange(N, device=dev).unsqueeze(1)
+    g = torch.arange(K // 16, device=dev).unsqueeze(0)
+    off = ((r // 128) * (K // 64) + g // 4) * 512 + (r % 32) * 16 + ((r // 32) % 4) * 4 + g % 4
+    sf = torch.zeros((Np, Kp // 16), dtype=torch.uint8, device=dev)
+    sf[:N, : K // 16] = SFW[off]
+    RB, T = Np // 16, Kp // 128
+    # codes: [RB, r, T, q, 16 B] -> [RB, T, q, r, 16 B]
+    RW = q.view(RB, 16, T, 4, 16).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+    # scales: a tile has 8 groups per row, lane (r, q) owns groups 2q and 2q + 1: [RB, r, T/2, 2 tiles, q, 2] -> [RB, T/2, q, r, tile, 2]
+    RSF = sf.view(RB, 16, T // 2, 2, 4, 2).permute(0, 2, 4, 1, 3, 5).contiguous().view(-1)
+    L = _lib.lib()
+    assert RW.numel() == L.arcq_repacked_w_bytes(N, K) and RSF.numel() == L.arcq_repacked_sf_bytes(N, K)
+    return RW, RSF
+
+
+def repacked_supported(M: int, N: int, K: int) -> bool:
+    """Whether ``matmul_repacked`` can run this shape (M <= 16 and the fp16 image of the activations fits LDS)."""
+    return bool(_lib.lib().arcq_gemm_repacked_supported(int(M), int(N), int(K)))
+
+
+def matmul_repacked(A: torch.Tensor, RW: torch.Tensor, SFA: torch.Tensor, RSF: torch.Tensor, scale, N: int, *, bias=None, residual=None,
+                    out_dtype=torch.bfloat16, out=None, scale_host: float = 1.0):
+    """``matmul`` for decode shapes over a weight prepared by ``repack_w`` (same arguments otherwise, plus the row count
+    ``N`` of the weight): the kernel streams the weight in MFMA operand order with no LDS transpose and no barrier in its
+    K loop.  Equals ``matmul`` on the un-repacked operands up to fp32 accumulation order."""
+    _need(A, torch.uint8, "A", 2)
+    _need(RW, torch.uint8, "RW", 1)
+    _need(SFA, torch.uint8, "SFA")
+    _need(RSF, torch.uint8, "RSF", 1)
+    M, K, N = A.shape[0], A.shape[1] * 2, int(N)
+    L = _lib.lib()
+    if K % 64 or RW.numel() != L.arcq_repacked_w_bytes(N, K) or RSF.numel() != L.arcq_repacked_sf_bytes(N, K):
+        raise RuntimeError(f"Value error in matmul_repacked: RW / RSF do not belong to a [{N}, {K}] weight")
+    if SFA.numel() < L.arcq_sf_used_bytes(M, K):
+        raise RuntimeError("Value error in matmul_repacked: SFA smaller than the swizzled layout of A")
+    if not L.arcq_gemm_repacked_supported(M, N, K):
+        raise RuntimeError(f"matmul_repacked: M={M}, K={K} is outside the repacked path (see repacked_supported)")
+    if out_dtype not in (torch.bfloat16, torch.float32):
+        raise RuntimeError("agemm.matmul_repacked: out_dtype must be bfloat16 or float32")
+    alpha_host, alpha_dev = float(scale_host), None
+    if isinstance(scale, torch.Tensor) and scale.is_cuda and scale.dtype == torch.float32 and scale.numel() == 1:
+        alpha_dev = scale
+    else:
+        alpha_host *= float(scale)
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+    elif tuple(out.shape) != (M, N) or out.dtype != out_dtype or not out.is_contiguous():
+        raise RuntimeError("agemm.matmul_repacked: out has the wrong shape / dtype")
+    if bias is not None:
+        _need(bias, torch.bfloat16, "bias", 1)
+        if bias.numel() != N:
+            raise RuntimeError("agemm.matmul_repacked: bias must have N entries")
+    if residual is not None:
+        _need(residual, torch.bfloat16, "residual", 2)
+        if tuple(residual.shape) != (M, N):
+            raise RuntimeError("agemm.matmul_repacked: residual must be [M, N]")
+    with torch.cuda.device(A.device):
+        st = L.arcq_gemm_nvfp4_repacked(A.data_ptr(), RW.data_ptr(), SFA.data_ptr(), RSF.data_ptr(), out.data_ptr(), M, N, K, alpha_host,
+                                        alpha_dev.data_ptr() if alpha_dev is not None else None,
+                                        bias.data_ptr() if bias is not None else None,
+                                        residual.data_ptr() if residual is not None else None,
+                                        OUT_BF16 if out_dtype == torch.bfloat16 else OUT_F32, _stream(A))
+    _lib.check(st, "matmul_repacked")
+    return out
+
+
 def matmul_silu_mul(A: torch.Tensor, B: torch.Tensor, SFA: torch.Tensor, SFB: torch.Tensor, scale, *, scale_host: float = 1.0):
     """Extension: the gate|up GEMM with the MLP's ``act_fn(gate) * up`` (SiLU, model/qLlamaLayer.py:417) in
     its epilogue.  ``B`` is the quantised weight whose ROWS INTERLEAVE gate and up (g0, u0, g1, u1, ...).  Returns

@@ -45,6 +45,11 @@ struct GemmArgs {
 };
 enum : int { kEpiPlain = 0, kEpiSiluMul = 1 };
 int64_t gemm_silu_slots(int64_t M, int64_t N, int64_t K);   // slots the silu-mul epilogue of this shape writes
+// gemm_rowblock.hip: decode GEMM over a weight repacked into MFMA-operand-order tiles (see arcq.h)
+int64_t gemm_repacked_w_bytes(int64_t N, int64_t K);
+int64_t gemm_repacked_sf_bytes(int64_t N, int64_t K);
+int gemm_repacked_supported(int64_t M, int64_t N, int64_t K);
+int gemm_repacked(const GemmArgs& a, const uint8_t* RW, const uint8_t* RSF, hipStream_t stream);
 int64_t gemm_skinny_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int64_t gemm_tile_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int64_t gemm_tile_silu_slots(int64_t M, int64_t N, int64_t K);

@@ -160,4 +160,29 @@ int arcq_quantize_x_dyn_slots(const void* X, const int16_t* reorder_index, uint8
   return quantize_x_dyn_slots(X, reorder_index, QX, SFX, scale_out, absmax_slots, nslots, M, KQ, KE, variant, (hipStream_t)stream);
 }
 
+int64_t arcq_repacked_w_bytes(int64_t N, int64_t K) { return (N > 0 && K > 0) ? gemm_repacked_w_bytes(N, K) : 0; }
+int64_t arcq_repacked_sf_bytes(int64_t N, int64_t K) { return (N > 0 && K > 0) ? gemm_repacked_sf_bytes(N, K) : 0; }
+int arcq_gemm_repacked_supported(int64_t M, int64_t N, int64_t K) { return gemm_repacked_supported(M, N, K); }
+
+int arcq_gemm_nvfp4_repacked(const uint8_t* A, const uint8_t* RW, const uint8_t* SFA, const uint8_t* RSF, void* D, int64_t M, int64_t N,
+                             int64_t K, float alpha_host, const float* alpha_dev, const void* bias, const void* residual, int out_dtype,
+                             void* stream) {
+  const char* who = "arcq_gemm_nvfp4_repacked";
+  if (M < 0 || N < 0 || K <= 0 || (K % 64))
+    return fail(ARCQ_ERR_SHAPE, "%s: need M,N >= 0 and K %% 64 == 0 (M=%lld N=%lld K=%lld)", who, (long long)M, (long long)N, (long long)K);
+  if (out_dtype != ARCQ_OUT_BF16 && out_dtype != ARCQ_OUT_F32) return fail(ARCQ_ERR_SHAPE, "%s: bad out_dtype %d", who, out_dtype);
+  if (M == 0 || N == 0) return ARCQ_OK;
+  if (!A || !RW || !SFA || !RSF || !D) return fail(ARCQ_ERR_NULL, "%s: NULL pointer", who);
+  if (N > INT32_MAX / 2 || K > INT32_MAX / 2) return fail(ARCQ_ERR_UNSUPPORTED, "%s: shape too large", who);
+  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(RW) | reinterpret_cast<uintptr_t>(D)) & 15)
+    return fail(ARCQ_ERR_SHAPE, "%s: A, RW and D must be 16-byte aligned", who);
+  if ((reinterpret_cast<uintptr_t>(SFA) | reinterpret_cast<uintptr_t>(RSF)) & 3) return fail(ARCQ_ERR_SHAPE, "%s: SFA and RSF must be 4-byte aligned", who);
+  GemmArgs a;
+  a.A = A; a.B = nullptr; a.SFA = SFA; a.SFB = nullptr; a.D = D;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K;
+  a.alpha_host = alpha_host; a.alpha_dev = alpha_dev; a.bias = (const uint16_t*)bias; a.residual = (const uint16_t*)residual; a.out_dtype = out_dtype;
+  a.workspace = nullptr; a.workspace_bytes = 0;
+  return gemm_repacked(a, RW, RSF, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -1,0 +1,210 @@
+// ARC-NVFP4 GEMM for decode shapes over a REPACKED weight: no LDS transpose, no barrier in the K loop.
+//
+// The reference layout (row-major packed codes, CUTLASS-swizzled scales; kernels/src/nvfp4.cu:35-132 consumes it through
+// TMA) forces the decode kernels of gemm_skinny.hip / gemm_decode.hip to fetch full 512-byte row segments and
+// transpose them to the MFMA operand layout through LDS: one barrier per item and ~92 instructions per 16 bytes of
+// weights, which is what bounds them (profiles/r01d_pmc_decode_gemm.json; the same weights served from the Infinity
+// Cache only gain 0-20 %).  Loading the operand layout directly from the row-major weight means 64-byte row segments:
+// 0.6-3.8 TB/s (tools/probe_rows.hip).  A weight is static, so it can be laid out for the hardware ONCE:
+//
+//   RW : tiles of 16 weight rows x 128 K elements = 1 KB, stored in MFMA operand order -- lane l = 16*q + r holds the
+//        16 bytes (32 codes) of row r, K elements [32q, 32q + 32) of the tile; tiles of one row block are consecutive,
+//        so a wave streams ONE contiguous span with fully coalesced global_load_dwordx4
+//   RSF: per PAIR of tiles 256 bytes: lane l holds the four ue4m3 bytes of its two 16-element groups in tile 2j and in
+//        tile 2j + 1 (one dword load per lane per two tiles)
+//   K is padded to a multiple of 256 with zero codes and zero scales, N to a multiple of 16 with zero scales.
+//   (arcquant_amd/agemm.py: repack_w builds both with torch ops from the reference layout; nothing is re-quantised.)
+//
+// Kernel: a workgroup of 8 waves first dequantises the M x K activations once into an fp16 LDS image (one barrier);
+// after that every wave is on its own: it owns (row block, K slice), streams its tiles through a 3-deep register ring
+// addressed by name (exactly counted vmcnt), dequantises in registers (exact, gemm_common.hpp), multiplies on
+// v_mfma_f32_16x16x32_f16 with the activation fragments read from the LDS image, and -- when a row block is split over
+// S waves -- adds the S partial tiles through LDS at the very end.  ~50 instructions per 16 bytes of weights.
+// Shapes: M <= 16 and an activation image that fits LDS (M * K_padded * 2 B <= ~128 KB); others use the other kernels.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "arcq_internal.hpp"
+#include "gemm_common.hpp"
+
+namespace arcq {
+
+struct RowblockParams {
+  const uint8_t* A;       // activations, reference layout [M, K/2]
+  const uint8_t* SFA;     // ... swizzled scales
+  const uint8_t* RW;      // repacked weight tiles
+  const uint8_t* RSF;     // repacked weight scales
+  void* D;
+  const float* alpha_dev;
+  const uint16_t* bias;
+  const uint16_t* residual;
+  int M, N, K;
+  float alpha_host;
+  int out_dtype;
+  int pairs;              // K_padded / 256: tile pairs per row block
+  int row_blocks;         // ceil(N / 16)
+  int slices;             // waves that share one row block (1, 2, 4 or 8)
+  int pairs_per_slice;
+  int a_stride;           // bytes per token row of the LDS image
+};
+
+typedef uint32_t rb_u32x4 __attribute__((ext_vector_type(4)));
+struct RowblockRegs {     // one tile pair of this lane: 2 x 16 bytes of codes, 4 scale bytes
+  rb_u32x4 b0, b1;
+  uint32_t s;
+};
+
+constexpr int kRbWaves = 8, kRbThreads = kRbWaves * 64;
+
+__global__ __launch_bounds__(kRbThreads, 4) void gemm_rowblock_kernel(RowblockParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const a_img = smem;                                        // [M][a_stride] fp16
+  float* const red = reinterpret_cast<float*>(smem + (size_t)p.M * p.a_stride);   // [8 waves][64][4] when slices > 1
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, rl = lane & 15;
+  const int bpw = kRbWaves / p.slices;                    // row blocks per workgroup
+  const int rb = blockIdx.x * bpw + wave / p.slices;
+  const int slice = wave % p.slices;
+  const bool active = rb < p.row_blocks;
+  const int pr_begin = min(slice * p.pairs_per_slice, p.pairs), pr_end = min(pr_begin + p.pairs_per_slice, p.pairs);
+  const int npairs = active ? pr_end - pr_begin : 0;
+  const float alpha = p.alpha_host * (p.alpha_dev ? *p.alpha_dev : 1.0f);
+
+  // ---- the weight stream starts before anything else: three tile pairs per lane in flight
+  const int rbc = active ? rb : 0;
+  const uint8_t* wp = p.RW + ((size_t)rbc * p.pairs + pr_begin) * 2048 + lane * 16;
+  const uint8_t* sp = p.RSF + ((size_t)rbc * p.pairs + pr_begin) * 256 + lane * 4;
+  const int last = npairs > 0 ? npairs - 1 : 0;
+  int issued = 0;
+  auto issue = [&](RowblockRegs& r) __attribute__((always_inline)) {       // unpredicated; the cursor stops at the last pair
+    const int i = min(issued, last);
+    r.b0 = *reinterpret_cast<const rb_u32x4*>(wp + (size_t)i * 2048);
+    r.b1 = *reinterpret_cast<const rb_u32x4*>(wp + (size_t)i * 2048 + 1024);
+    r.s = *reinterpret_cast<const uint32_t*>(sp + (size_t)i * 256);
+    ++issued;
+  };
+  RowblockRegs r0, r1, r2;
+  issue(r0);
+  issue(r1);
+  issue(r2);
+
+  // ---- activation image: unit = 32 elements (16 packed bytes, two scale bytes) -> 64 bytes of fp16
+  {
+    const int upr = p.pairs * 8, real = p.K >> 5;          // units per token row (padded) / holding real data
+    const int atoms_k = p.K >> 6;
+    for (int u = tid; u < p.M * upr; u += kRbThreads) {
+      const int m = u / upr, c = u - m * upr;
+      uint4 f0 = make_uint4(0, 0, 0, 0), f1 = f0, f2 = f0, f3 = f0;
+      if (c < real) {
+        const uint4 qv = *reinterpret_cast<const uint4*>(p.A + (size_t)m * (p.K >> 1) + c * 16);
+        const uint32_t sf = *reinterpret_cast<const uint16_t*>(p.SFA + sf_atom_offset(m, c >> 1, atoms_k) + (c & 1) * 2);
+        const f16x2 s0 = sf_pair_at(sf, 0), s1 = sf_pair_at(sf, 8);
+        f0 = dequant8(qv.x, s0).u; f1 = dequant8(qv.y, s0).u; f2 = dequant8(qv.z, s1).u; f3 = dequant8(qv.w, s1).u;
+      }
+      uint4* dst = reinterpret_cast<uint4*>(a_img + (size_t)m * p.a_stride + c * 64);
+      dst[0] = f0; dst[1] = f1; dst[2] = f2; dst[3] = f3;
+    }
+  }
+  __syncthreads();
+
+  // ---- K loop: no barrier, no LDS traffic for the weights
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const unsigned char* a_lane = a_img + (size_t)min(rl, p.M - 1) * p.a_stride + (size_t)pr_begin * 512 + q * 64;   // tokens >= M: any row
+  int done = 0;
+  auto tile = [&](rb_u32x4 b, uint32_t s16, const unsigned char* ap) __attribute__((always_inline)) {
+    Frag8 a0, a1, a2, a3;
+    a0.u = *reinterpret_cast<const uint4*>(ap);
+    a1.u = *reinterpret_cast<const uint4*>(ap + 16);
+    a2.u = *reinterpret_cast<const uint4*>(ap + 32);
+    a3.u = *reinterpret_cast<const uint4*>(ap + 48);
+    const f16x2 s0 = sf_pair_at(s16, 0), s1 = sf_pair_at(s16, 8);
+    const Frag8 b0 = dequant8(b.x, s0), b1 = dequant8(b.y, s0), b2 = dequant8(b.z, s1), b3 = dequant8(b.w, s1);
+    // weights are the MFMA A operand (rows = weight rows), activations the B operand (columns = tokens)
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0.v, a0.v, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1.v, a1.v, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b2.v, a2.v, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b3.v, a3.v, acc, 0, 0, 0);
+  };
+  auto step = [&](RowblockRegs& r) __attribute__((always_inline)) {
+    const unsigned char* ap = a_lane + (size_t)done * 512;
+    tile(r.b0, r.s, ap);
+    tile(r.b1, r.s >> 16, ap + 256);
+    issue(r);                                               // refill: three pairs ahead
+    ++done;
+  };
+#pragma unroll 1
+  while (done + 3 <= npairs) {
+    step(r0);
+    step(r1);
+    step(r2);
+  }
+  if (done < npairs) step(r0);
+  if (done < npairs) step(r1);
+
+  // ---- lane holds C[token = rl][row = 16 rb + 4q + e]; add the K slices of a row block through LDS
+  float sum[4] = {acc[0], acc[1], acc[2], acc[3]};
+  if (p.slices > 1) {
+    *reinterpret_cast<float4*>(red + (wave * 64 + lane) * 4) = make_float4(sum[0], sum[1], sum[2], sum[3]);
+    __syncthreads();
+    if (slice != 0) return;
+    for (int s2 = 1; s2 < p.slices; ++s2) {
+      const float4 v = *reinterpret_cast<const float4*>(red + ((wave + s2) * 64 + lane) * 4);
+      sum[0] += v.x; sum[1] += v.y; sum[2] += v.z; sum[3] += v.w;
+    }
+  }
+  const int n0 = rb * 16 + 4 * q;
+  if (active && rl < p.M && n0 < p.N) finish4<uint32_t>(p, alpha, rl, n0, sum);
+}
+
+// Repacked sizes: rows padded to 16, K to 256.
+static int64_t rowblock_pairs(int64_t K) { return (K + 255) / 256; }
+int64_t gemm_repacked_w_bytes(int64_t N, int64_t K) { return ((N + 15) / 16) * rowblock_pairs(K) * 2048; }
+int64_t gemm_repacked_sf_bytes(int64_t N, int64_t K) { return ((N + 15) / 16) * rowblock_pairs(K) * 256; }
+
+static int rowblock_lds_bytes(int M, int64_t K, int slices, int* a_stride) {
+  const int stride = (int)(rowblock_pairs(K) * 512 + 16);          // + 16: token rows start in different banks
+  *a_stride = stride;
+  return M * stride + (slices > 1 ? kRbWaves * 64 * 4 * (int)sizeof(float) : 0);
+}
+
+// 1 = this shape can run on the repacked path (M <= 16 and the fp16 activation image fits LDS)
+int gemm_repacked_supported(int64_t M, int64_t N, int64_t K) {
+  if (M < 1 || M > 16 || N < 1 || K < 64 || (K % 64)) return 0;
+  int stride;
+  return rowblock_lds_bytes((int)M, K, 8, &stride) <= 150 * 1024 ? 1 : 0;
+}
+
+int gemm_repacked(const GemmArgs& a, const uint8_t* RW, const uint8_t* RSF, hipStream_t stream) {
+  if (!gemm_repacked_supported(a.M, a.N, a.K))
+    return fail(ARCQ_ERR_UNSUPPORTED, "arcq_gemm_nvfp4_repacked: M=%d K=%d outside the repacked path (M <= 16, activation image <= 150 KB)", a.M, a.K);
+  RowblockParams p;
+  p.A = a.A; p.SFA = a.SFA; p.RW = RW; p.RSF = RSF; p.D = a.D;
+  p.alpha_dev = a.alpha_dev; p.bias = a.bias; p.residual = a.residual;
+  p.M = a.M; p.N = a.N; p.K = a.K; p.alpha_host = a.alpha_host; p.out_dtype = a.out_dtype;
+  p.pairs = (int)rowblock_pairs(a.K);
+  p.row_blocks = (a.N + 15) / 16;
+  // waves per row block: enough wave tasks to occupy 256 CUs x 16 waves, at least two tile pairs per wave
+  static const int forced = getenv("ARCQ_ROWBLOCK_SLICES") ? atoi(getenv("ARCQ_ROWBLOCK_SLICES")) : 0;   // tuning only
+  int s = 1;
+  while (s < 8 && (int64_t)p.row_blocks * s < 3072 && p.pairs / (s * 2) >= 2) s *= 2;
+  if (forced == 1 || forced == 2 || forced == 4 || forced == 8) s = forced;
+  p.slices = s;
+  p.pairs_per_slice = (p.pairs + s - 1) / s;
+  const int lds = rowblock_lds_bytes(a.M, a.K, s, &p.a_stride);
+  static int lds_set = 0;
+  if (lds > 48 * 1024 && lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rowblock_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_gemm_nvfp4_repacked: cannot reserve %d B of LDS: %s", lds, hipGetErrorString(e));
+    lds_set = lds;
+  }
+  const int bpw = kRbWaves / s;
+  const int grid = (p.row_blocks + bpw - 1) / bpw;
+  hipLaunchKernelGGL(gemm_rowblock_kernel, dim3((unsigned)grid), dim3(kRbThreads), lds, stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_gemm_nvfp4_repacked: launch failed: %s", hipGetErrorString(e));
+  return ARCQ_OK;
+}
+
+}  // namespace arcq

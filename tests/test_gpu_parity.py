@@ -478,6 +478,39 @@ def test_decode_and_tile_kernels_agree_and_full_residual_width():
     assert torch.allclose(big[:16], small, rtol=1e-5, atol=1e-5 * float(big.abs().max()))
 
 
+def test_repacked_weight_gemm_equals_the_reference_layout_gemm():
+    """repack_w is pure data movement and matmul_repacked contracts the same exact products: its fp32 output equals the
+    oracle within accumulation noise and matmul's within a few ulp, bf16 within one ulp; bias / residual / device scale
+    behave alike; shapes cover one to eight waves per row block, ragged N, K % 256 in {0, 64, 128, 192}."""
+    ag = _agemm()
+    cases = [(1, 512, 256, 64, O.G16), (4, 100, 256, 64, O.G16), (3, 1000, 64, 0, O.G16), (16, 272, 1024, 64, O.G16),
+             (8, 777, 512, 64, O.G16), (4, 3584, 3584, 64, O.G32), (2, 52000, 256, 64, O.G16), (5, 5120, 384, 0, O.G16)]
+    for (M, N, KQ, KE, variant) in cases:
+        K = KQ + KE
+        assert ag.repacked_supported(M, N, K)
+        qx, sfx, qw, sfw, alpha = _make_operands(M, N, KQ, KE, variant, 77 + M + N)
+        A, B = torch.from_numpy(qx).to(DEV), torch.from_numpy(qw).to(DEV)
+        SFA, SFB = torch.from_numpy(sfx).to(DEV), torch.from_numpy(sfw).to(DEV)
+        RW, RSF = ag.repack_w(B, SFB)
+        ref32 = ag.matmul(A, B, SFA, SFB, alpha, out_dtype=torch.float32)
+        got32 = ag.matmul_repacked(A, RW, SFA, RSF, alpha, N, out_dtype=torch.float32)
+        assert got32.shape == (M, N)
+        if N * K <= 4_000_000:
+            _, want, wabs = O.gemm(qx, qw, sfx, sfw, alpha, want_abs=True)
+            assert np.all(np.abs(got32.cpu().numpy() - want) <= 2e-6 * wabs + 1e-30), (M, N, K)
+        assert torch.allclose(got32, ref32, rtol=2e-5, atol=2e-6 * float(ref32.abs().max())), (M, N, K)
+        g = torch.Generator().manual_seed(N)
+        bias = torch.randn(N, generator=g).to(torch.bfloat16).to(DEV)
+        res = torch.randn(M, N, generator=g).to(torch.bfloat16).to(DEV)
+        dev_scale = torch.tensor(alpha / 0.5, dtype=torch.float32, device=DEV)
+        want16 = res + (got32 + bias.float()).to(torch.bfloat16)
+        got16 = ag.matmul_repacked(A, RW, SFA, RSF, dev_scale, N, scale_host=0.5, bias=bias, residual=res)
+        assert torch.equal(got16, want16), (M, N, K)
+    assert not ag.repacked_supported(17, 256, 256) and not ag.repacked_supported(16, 256, 19008)
+    with pytest.raises(RuntimeError):
+        ag.matmul_repacked(A, RW[:-1], SFA, RSF, alpha, N)
+
+
 def test_silu_mul_gemm_epilogue_equals_the_unfused_steps():
     """matmul_silu_mul on row-interleaved gate/up weights == matmul, then torch's silu and mul, bit for bit; its abs-max
     slots give the dynamic quantiser the same scale and bytes as the abs-max pass (decode kernel, 64-row, 128x128 and
