@@ -132,6 +132,7 @@ __global__ __launch_bounds__(kRbThreads, 4) void gemm_rowblock_kernel(RowblockPa
     tile(r.b0, r.s, ap);
     tile(r.b1, r.s >> 16, ap + 256);
     issue(r);                                               // refill: three pairs ahead
+    __builtin_amdgcn_sched_barrier(0);                      // hipcc otherwise sinks all refills to the end of the unrolled body
     ++done;
   };
 #pragma unroll 1
@@ -185,10 +186,12 @@ int gemm_repacked(const GemmArgs& a, const uint8_t* RW, const uint8_t* RSF, hipS
   p.M = a.M; p.N = a.N; p.K = a.K; p.alpha_host = a.alpha_host; p.out_dtype = a.out_dtype;
   p.pairs = (int)rowblock_pairs(a.K);
   p.row_blocks = (a.N + 15) / 16;
-  // waves per row block: enough wave tasks to occupy 256 CUs x 16 waves, at least two tile pairs per wave
+  // waves per row block: split while that still leaves <= 2048 wave tasks (half the chip's wave slots) or >= 7 tile pairs
+  // per wave.  Measured (tools/repacked_bench.py, us): N=37888 K=3648 S=1/2/4: 23.7 / 20.6 / 23.5; N=10752: 11.5 / 8.8 / 10.0;
+  // N=4096 K=4160: 10.7 / 7.8 / 6.4 / 6.1 (S=8).
   static const int forced = getenv("ARCQ_ROWBLOCK_SLICES") ? atoi(getenv("ARCQ_ROWBLOCK_SLICES")) : 0;   // tuning only
   int s = 1;
-  while (s < 8 && (int64_t)p.row_blocks * s < 3072 && p.pairs / (s * 2) >= 2) s *= 2;
+  while (s < 8 && p.pairs / (s * 2) >= 1 && ((int64_t)p.row_blocks * s * 2 <= 2048 || p.pairs / (s * 2) >= 7)) s *= 2;
   if (forced == 1 || forced == 2 || forced == 4 || forced == 8) s = forced;
   p.slices = s;
   p.pairs_per_slice = (p.pairs + s - 1) / s;

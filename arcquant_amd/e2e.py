@@ -60,6 +60,19 @@ class QLinear:
         self.scale = scale.reshape(1)
         self.scale_f = float(scale)          # one sync at load time; lets alpha = scale_f * (device activation scale)
         self.in_f, self.out_f, self.KE = in_f, out_f, select_num
+        self.RW = self.RSF = None
+
+    def repack(self):
+        """Second copy of the weight in MFMA-operand-order tiles for the decode path (agemm.repack_w): worth its memory
+        where the repacked kernel wins (measured: N >= 4096; the 3584 x 3648 o-projection is 0.5 us slower)."""
+        if self.out_f >= 4096:
+            self.RW, self.RSF = agemm.repack_w(self.W, self.SFW)
+
+    def matmul(self, A, SFA, scale, **kw):
+        """GEMM against this weight: the repacked kernel for decode-sized token counts where available."""
+        if self.RW is not None and agemm.repacked_supported(A.shape[0], self.out_f, self.in_f + self.KE):
+            return agemm.matmul_repacked(A, self.RW, SFA, self.RSF, scale, self.out_f, **kw)
+        return agemm.matmul(A, self.W, SFA, self.SFW, scale, **kw)
 
     def bytes(self):
         return self.W.numel() + self.out_f * (self.in_f + self.KE) // 16
@@ -88,6 +101,10 @@ class DecoderModel:
                 o=QLinear(h, h, ke, device, g), down=QLinear(it, h, ke, device, g),
                 kv=torch.zeros(2, batch, cfg.num_heads, max_len, h // cfg.num_heads, dtype=torch.bfloat16, device=device)))
             self.layers[-1]["kc"], self.layers[-1]["vc"] = self.layers[-1]["kv"][0], self.layers[-1]["kv"][1]
+        if fused:
+            for L in self.layers:
+                for name in ("qkv", "o", "gateup", "down"):
+                    L[name].repack()
         self.idx_h = torch.arange(h, dtype=torch.int16, device=device)
         self.idx_i = torch.arange(it, dtype=torch.int16, device=device)
         self.norm = torch.ones(h, dtype=torch.bfloat16, device=device)
@@ -116,7 +133,7 @@ class DecoderModel:
         for L in self.layers:
             A, SFA = agemm.rmsnorm_quantize_x(hcur, L["ln1"], cfg.eps, self.idx_h, cfg.select_num)
             if self.fused:
-                qkv = agemm.matmul(A, L["qkv"].W, SFA, L["qkv"].SFW, L["qkv"].scale)
+                qkv = L["qkv"].matmul(A, SFA, L["qkv"].scale)
                 q, k, v = qkv[:, :h], qkv[:, h:2 * h], qkv[:, 2 * h:]
             else:
                 q = agemm.matmul(A, L["q"].W, SFA, L["q"].SFW, L["q"].scale)
@@ -137,7 +154,7 @@ class DecoderModel:
             att = att.transpose(1, 2).reshape(bsz * q_len, cfg.hidden_size)
             if self.fused:
                 qa, sfa, sa = agemm.reorder_quantize_x_dynamic(att, self.idx_h, cfg.select_num)
-                hcur = agemm.matmul(qa, L["o"].W, sfa, L["o"].SFW, sa, scale_host=L["o"].scale_f, residual=hcur)
+                hcur = L["o"].matmul(qa, sfa, sa, scale_host=L["o"].scale_f, residual=hcur)
             else:
                 qa, sfa, sa = self._quant_x(att, self.idx_h, cfg.select_num)
                 hcur = hcur + agemm.matmul(qa, L["o"].W, sfa, L["o"].SFW, sa * L["o"].scale)
@@ -148,9 +165,9 @@ class DecoderModel:
                     act, slots = agemm.matmul_silu_mul(A, L["gateup"].W, SFA, L["gateup"].SFW, L["gateup"].scale)
                     qa, sfa, sa = agemm.reorder_quantize_x_dynamic(act, self.idx_i, cfg.select_num, absmax_slots=slots)
                 else:                   # decode: the exp-heavy epilogue would sit on the streaming kernel's critical path
-                    gu = agemm.matmul(A, L["gateup"].W, SFA, L["gateup"].SFW, L["gateup"].scale)      # measured 29.0 vs 22.8 us
+                    gu = L["gateup"].matmul(A, SFA, L["gateup"].scale)                                # measured 29.0 vs 22.8 us
                     qa, sfa, sa = agemm.silu_mul_quantize_x_dynamic(gu, self.idx_i, cfg.select_num, layout=agemm.GU_PAIRS)
-                hcur = agemm.matmul(qa, L["down"].W, sfa, L["down"].SFW, sa, scale_host=L["down"].scale_f, residual=hcur)
+                hcur = L["down"].matmul(qa, sfa, sa, scale_host=L["down"].scale_f, residual=hcur)
             else:
                 gate = agemm.matmul(A, L["gate"].W, SFA, L["gate"].SFW, L["gate"].scale)
                 up = agemm.matmul(A, L["up"].W, SFA, L["up"].SFW, L["up"].scale)
