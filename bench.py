@@ -132,6 +132,20 @@ def bench_extra(args, device, rank):
         extra[f"decode_gemm_M{m}_N{n}_KQ{kq}"] = {"us_per_launch_graph": round(t, 3), "GBps": round(gb / t / 1e3, 1),
                                                  "frac_hbm_peak": round(gb / t / 1e3 / PEAK_HBM_GBS, 4)}
         del qws, sfws, q, launches
+    # ---- the same decode shapes over the repacked weight (agemm.repack_w / matmul_repacked), where that path applies
+    for (m, n, kq) in [(1, 4096, 4096), (1, 14336, 4096), (1, 4096, 14336), (4, 10752, 3584), (4, 37888, 3584)]:
+        if not agemm.repacked_supported(m, n, kq + KE):
+            continue
+        q = make_problem(m, n, kq, KE, device)
+        rot = max(2, int(320e6 // (n * (kq + KE) * 9 / 16)) + 1)
+        rps = [agemm.repack_w(q["qw"].clone(), q["sfw"].clone()) for _ in range(rot)]
+        o = torch.empty((m, n), dtype=torch.bfloat16, device=device)
+        launches = [(lambda i=i: agemm.matmul_repacked(q["qx"], rps[i][0], q["sfx"], rps[i][1], q["alpha"], n, out=o)) for i in range(rot)]
+        t = graph_time(launches)
+        gb = gemm_bytes(m, n, kq + KE)
+        extra[f"decode_gemm_repacked_M{m}_N{n}_KQ{kq}"] = {"us_per_launch_graph": round(t, 3), "GBps": round(gb / t / 1e3, 1),
+                                                          "frac_hbm_peak": round(gb / t / 1e3 / PEAK_HBM_GBS, 4)}
+        del rps, q, launches
     extra["decode_note"] = (f"HIP-graph replay over weight copies totalling > 320 MB; per-launch time includes the inter-kernel gap; "
                             f"floor of a read-only kernel for 9.6 MB is 3.3 us (tools/probe_stream.hip)")
 
