@@ -20,7 +20,7 @@
 // addressed by name (exactly counted vmcnt), dequantises in registers (exact, gemm_common.hpp), multiplies on
 // v_mfma_f32_16x16x32_f16 with the activation fragments read from the LDS image, and -- when a row block is split over
 // S waves -- adds the S partial tiles through LDS at the very end.  ~50 instructions per 16 bytes of weights.
-// Shapes: M <= 16 and an activation image that fits LDS (M * K_padded * 2 B <= ~128 KB); others use the other kernels.
+// Shapes: M <= 16 and an activation image that fits LDS (M * K_padded * 2 B <= 160 KB); others use the other kernels.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -60,7 +60,7 @@ constexpr int kRbWaves = 8, kRbThreads = kRbWaves * 64;
 __global__ __launch_bounds__(kRbThreads, 4) void gemm_rowblock_kernel(RowblockParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const a_img = smem;                                        // [M][a_stride] fp16
-  float* const red = reinterpret_cast<float*>(smem + (size_t)p.M * p.a_stride);   // [8 waves][64][4] when slices > 1
+  float* const red = reinterpret_cast<float*>(smem);    // [8 waves][64][4] when slices > 1: REUSES the image after the K loop
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, rl = lane & 15;
@@ -147,6 +147,7 @@ __global__ __launch_bounds__(kRbThreads, 4) void gemm_rowblock_kernel(RowblockPa
   // ---- lane holds C[token = rl][row = 16 rb + 4q + e]; add the K slices of a row block through LDS
   float sum[4] = {acc[0], acc[1], acc[2], acc[3]};
   if (p.slices > 1) {
+    __syncthreads();                                        // every wave is done reading the activation image
     *reinterpret_cast<float4*>(red + (wave * 64 + lane) * 4) = make_float4(sum[0], sum[1], sum[2], sum[3]);
     __syncthreads();
     if (slice != 0) return;
@@ -167,19 +168,20 @@ int64_t gemm_repacked_sf_bytes(int64_t N, int64_t K) { return ((N + 15) / 16) * 
 static int rowblock_lds_bytes(int M, int64_t K, int slices, int* a_stride) {
   const int stride = (int)(rowblock_pairs(K) * 512 + 16);          // + 16: token rows start in different banks
   *a_stride = stride;
-  return M * stride + (slices > 1 ? kRbWaves * 64 * 4 * (int)sizeof(float) : 0);
+  const int red = slices > 1 ? kRbWaves * 64 * 4 * (int)sizeof(float) : 0;      // aliased onto the image
+  return M * stride > red ? M * stride : red;
 }
 
 // 1 = this shape can run on the repacked path (M <= 16 and the fp16 activation image fits LDS)
 int gemm_repacked_supported(int64_t M, int64_t N, int64_t K) {
   if (M < 1 || M > 16 || N < 1 || K < 64 || (K % 64)) return 0;
   int stride;
-  return rowblock_lds_bytes((int)M, K, 8, &stride) <= 150 * 1024 ? 1 : 0;
+  return rowblock_lds_bytes((int)M, K, 8, &stride) <= 160 * 1024 ? 1 : 0;
 }
 
 int gemm_repacked(const GemmArgs& a, const uint8_t* RW, const uint8_t* RSF, hipStream_t stream) {
   if (!gemm_repacked_supported(a.M, a.N, a.K))
-    return fail(ARCQ_ERR_UNSUPPORTED, "arcq_gemm_nvfp4_repacked: M=%d K=%d outside the repacked path (M <= 16, activation image <= 150 KB)", a.M, a.K);
+    return fail(ARCQ_ERR_UNSUPPORTED, "arcq_gemm_nvfp4_repacked: M=%d K=%d outside the repacked path (M <= 16, activation image <= 160 KB)", a.M, a.K);
   RowblockParams p;
   p.A = a.A; p.SFA = a.SFA; p.RW = RW; p.RSF = RSF; p.D = a.D;
   p.alpha_dev = a.alpha_dev; p.bias = a.bias; p.residual = a.residual;

@@ -484,7 +484,8 @@ def test_repacked_weight_gemm_equals_the_reference_layout_gemm():
     behave alike; shapes cover one to eight waves per row block, ragged N, K % 256 in {0, 64, 128, 192}."""
     ag = _agemm()
     cases = [(1, 512, 256, 64, O.G16), (4, 100, 256, 64, O.G16), (3, 1000, 64, 0, O.G16), (16, 272, 1024, 64, O.G16),
-             (8, 777, 512, 64, O.G16), (4, 3584, 3584, 64, O.G32), (2, 52000, 256, 64, O.G16), (5, 5120, 384, 0, O.G16)]
+             (8, 777, 512, 64, O.G16), (4, 3584, 3584, 64, O.G32), (2, 52000, 256, 64, O.G16), (5, 5120, 384, 0, O.G16),
+             (4, 256, 18944, 64, O.G32)]        # the last: a 153.7 KB activation image (Qwen2.5-7B down-projection at bs=4)
     for (M, N, KQ, KE, variant) in cases:
         K = KQ + KE
         assert ag.repacked_supported(M, N, K)
@@ -506,7 +507,7 @@ def test_repacked_weight_gemm_equals_the_reference_layout_gemm():
         want16 = res + (got32 + bias.float()).to(torch.bfloat16)
         got16 = ag.matmul_repacked(A, RW, SFA, RSF, dev_scale, N, scale_host=0.5, bias=bias, residual=res)
         assert torch.equal(got16, want16), (M, N, K)
-    assert not ag.repacked_supported(17, 256, 256) and not ag.repacked_supported(16, 256, 19008)
+    assert not ag.repacked_supported(17, 256, 256) and not ag.repacked_supported(5, 256, 19008)
     with pytest.raises(RuntimeError):
         ag.matmul_repacked(A, RW[:-1], SFA, RSF, alpha, N)
 
