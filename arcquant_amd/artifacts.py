@@ -234,6 +234,8 @@ def restore_qlinear(entry: dict):
     m.register_buffer("W", entry["W"])
     m.register_buffer("scale_w", entry["scale_w"])
     m.register_buffer("scale", entry["scale"])
+    m.register_buffer("RW", None)            # the optional decode copy is rebuilt on demand (agemm.repack_w), not cached
+    m.register_buffer("RSF", None)
     return m
 
 

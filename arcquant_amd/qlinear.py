@@ -56,7 +56,11 @@ def find_qlinear_layers(module, name=""):
 class QLinearLayer(nn.Module):
     """Weight quantised once at construction; forward = ARC-NVFP4 GEMM (+ bias) on pre-quantised activations."""
 
-    def __init__(self, originalLayer: nn.Linear, select_num, reorder_index, out_reorder_index=None, quant_type="NVFP4"):
+    def __init__(self, originalLayer: nn.Linear, select_num, reorder_index, out_reorder_index=None, quant_type="NVFP4",
+                 repack_for_decode: bool = False):
+        """``repack_for_decode`` (extension, default off = the reference's behaviour and memory): additionally keep the
+        weight in MFMA-operand-order tiles (``agemm.repack_w``) and use ``agemm.matmul_repacked`` for calls of at most 16
+        tokens."""
         super().__init__()
         if quant_type != "NVFP4":
             raise NotImplementedError("only quant_type='NVFP4' is supported")
@@ -77,11 +81,17 @@ class QLinearLayer(nn.Module):
         self.register_buffer("W", W)
         self.register_buffer("scale_w", scale_w)
         self.register_buffer("scale", scale)
+        RW, RSF = agemm.repack_w(W, scale_w) if repack_for_decode else (None, None)
+        self.register_buffer("RW", RW)
+        self.register_buffer("RSF", RSF)
 
     @torch.no_grad()
     def forward(self, x):
         qx, scale_x, scale, bsz, q_len = x
-        y = agemm.matmul(qx, self.W, scale_x, self.scale_w, scale * self.scale)
+        if getattr(self, "RW", None) is not None and agemm.repacked_supported(qx.shape[0], self.out_features, qx.shape[1] * 2):
+            y = agemm.matmul_repacked(qx, self.RW, scale_x, self.RSF, scale * self.scale, self.out_features)
+        else:
+            y = agemm.matmul(qx, self.W, scale_x, self.scale_w, scale * self.scale)
         if self.bias is not None:
             y = y + self.bias
         return y.reshape(bsz, q_len, -1)

@@ -133,7 +133,7 @@ def bench_extra(args, device, rank):
                                                  "frac_hbm_peak": round(gb / t / 1e3 / PEAK_HBM_GBS, 4)}
         del qws, sfws, q, launches
     # ---- the same decode shapes over the repacked weight (agemm.repack_w / matmul_repacked), where that path applies
-    for (m, n, kq) in [(1, 4096, 4096), (1, 14336, 4096), (1, 4096, 14336), (4, 10752, 3584), (4, 37888, 3584)]:
+    for (m, n, kq) in [(1, 4096, 4096), (1, 14336, 4096), (1, 4096, 14336), (4, 10752, 3584), (4, 37888, 3584), (4, 3584, 18944)]:
         if not agemm.repacked_supported(m, n, kq + KE):
             continue
         q = make_problem(m, n, kq, KE, device)

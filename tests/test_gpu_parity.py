@@ -364,6 +364,11 @@ def test_qlinear_layer_mirror_matches_oracle_pipeline():
     want = (from_bits(want_bits) + lin.bias.data.cpu()).reshape(bsz, q_len, N)      # bias added after rounding, as the reference
     assert _max_bf16_ulp_diff(bits(y), bits(want)) <= 2
     assert (bits(y) == bits(want)).mean() > 0.98
+    # the optional decode copy of the weight gives the same layer output (up to fp32 accumulation order)
+    fast = qlinear.QLinearLayer(lin, KE, idx, repack_for_decode=True)
+    assert fast.RW is not None and torch.equal(fast.W, layer.W)
+    y2 = fast((qx, scale_x, scale, bsz, q_len))
+    assert _max_bf16_ulp_diff(bits(y2), bits(y)) <= 1 and (bits(y2) == bits(y)).mean() > 0.99
 
 
 def test_gemm_with_subnormal_and_extreme_scales():
