@@ -72,7 +72,15 @@ __global__ __launch_bounds__(kRbThreads, 4) void gemm_rowblock_kernel(RowblockPa
   const int npairs = active ? pr_end - pr_begin : 0;
   const float alpha = p.alpha_host * (p.alpha_dev ? *p.alpha_dev : 1.0f);
 
-  // ---- the weight stream starts before anything else: three tile pairs per lane in flight
+  // ---- this thread's first unit of the activation image is requested FIRST: a wave's loads return in order, so behind
+  //      the nine weight loads below it would only arrive with them (HBM latency) instead of at L2 latency
+  const int upr = p.pairs * 8, real = p.K >> 5;            // image units (32 elements) per token row: padded / real
+  const int atoms_k = p.K >> 6;
+  const int m0 = min(tid / upr, p.M - 1), c0 = tid % upr, c0c = min(c0, real - 1);
+  const uint4 qv0 = *reinterpret_cast<const uint4*>(p.A + (size_t)m0 * (p.K >> 1) + c0c * 16);
+  const uint32_t sfw0 = *reinterpret_cast<const uint32_t*>(p.SFA + sf_atom_offset(m0, c0c >> 1, atoms_k));   // the atom's 4 bytes
+
+  // ---- then the weight stream: three tile pairs per lane in flight
   const int rbc = active ? rb : 0;
   const uint8_t* wp = p.RW + ((size_t)rbc * p.pairs + pr_begin) * 2048 + lane * 16;
   const uint8_t* sp = p.RSF + ((size_t)rbc * p.pairs + pr_begin) * 256 + lane * 4;
@@ -92,14 +100,17 @@ __global__ __launch_bounds__(kRbThreads, 4) void gemm_rowblock_kernel(RowblockPa
 
   // ---- activation image: unit = 32 elements (16 packed bytes, two scale bytes) -> 64 bytes of fp16
   {
-    const int upr = p.pairs * 8, real = p.K >> 5;          // units per token row (padded) / holding real data
-    const int atoms_k = p.K >> 6;
     for (int u = tid; u < p.M * upr; u += kRbThreads) {
       const int m = u / upr, c = u - m * upr;
       uint4 f0 = make_uint4(0, 0, 0, 0), f1 = f0, f2 = f0, f3 = f0;
       if (c < real) {
-        const uint4 qv = *reinterpret_cast<const uint4*>(p.A + (size_t)m * (p.K >> 1) + c * 16);
-        const uint32_t sf = *reinterpret_cast<const uint16_t*>(p.SFA + sf_atom_offset(m, c >> 1, atoms_k) + (c & 1) * 2);
+        uint4 qv = qv0;
+        uint32_t sf = sfw0;
+        if (u != tid) {                                     // second and later units of a thread (large M * K only)
+          qv = *reinterpret_cast<const uint4*>(p.A + (size_t)m * (p.K >> 1) + c * 16);
+          sf = *reinterpret_cast<const uint32_t*>(p.SFA + sf_atom_offset(m, c >> 1, atoms_k));
+        }
+        sf >>= (c & 1) * 16;
         const f16x2 s0 = sf_pair_at(sf, 0), s1 = sf_pair_at(sf, 8);
         f0 = dequant8(qv.x, s0).u; f1 = dequant8(qv.y, s0).u; f2 = dequant8(qv.z, s1).u; f3 = dequant8(qv.w, s1).u;
       }

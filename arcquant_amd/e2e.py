@@ -63,10 +63,8 @@ class QLinear:
         self.RW = self.RSF = None
 
     def repack(self):
-        """Second copy of the weight in MFMA-operand-order tiles for the decode path (agemm.repack_w): worth its memory
-        where the repacked kernel wins (measured: N >= 4096; the 3584 x 3648 o-projection is 0.5 us slower)."""
-        if self.out_f >= 4096 or self.in_f >= 8192:
-            self.RW, self.RSF = agemm.repack_w(self.W, self.SFW)
+        """Second copy of the weight in MFMA-operand-order tiles for the decode path (agemm.repack_w)."""
+        self.RW, self.RSF = agemm.repack_w(self.W, self.SFW)
 
     def matmul(self, A, SFA, scale, **kw):
         """GEMM against this weight: the repacked kernel for decode-sized token counts where available."""
