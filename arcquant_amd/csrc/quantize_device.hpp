@@ -1,0 +1,69 @@
+// Per-group NVFP4 quantisation shared by the quantiser kernels (quantize.hip) and by the GEMM whose prologue quantises
+// its own activations (gemm_rowblock.hip): ONE statement of the arithmetic, so both produce the same bytes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "arcq_device.hpp"
+#include "arcq_internal.hpp"
+
+namespace arcq {
+
+struct GroupQ {
+  uint2 packed;    // 16 e2m1 codes, low nibble = even element (reorder.cu:28-31)
+  uint32_t s8;     // ue4m3 scale byte
+  float s_round;   // decoded ue4m3 scale
+  float s_raw;     // clamp(amax/6, 2^-9, 448) before rounding
+};
+
+// amax -> scale -> codes for one 16-element group held in registers (reorder.cu:119-164).
+// When kResid, v[] is overwritten with bf16(v - q*S), S = rounded scale (G16) or raw scale (G32).
+template <bool kResid, int kVariant>
+__device__ __forceinline__ GroupQ quantize_group(float (&v)[16]) {
+  float amax = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(v[i]));
+  float s = amax / kFp4Max;                      // IEEE division (hipcc default: correctly rounded)
+  s = fminf(fmaxf(s, kScaleEps), kFp8Max);
+  GroupQ g;
+  g.s_raw = s;
+  // gfx950 conversion instructions, probed (tools/probe_gfx950.hip) and byte-checked against the oracle by the GPU
+  // tests: v_cvt_pk_fp8_f32 is OCP e4m3 RNE incl. subnormals (s is already clamped to [2^-9, 448]);
+  // v_cvt_scalef32_pk_fp4_f32 is RNE, ties to the even code, saturating at +-6 (== clamp then convert,
+  // reorder.cu:153), sign of zero kept; v_cvt_scalef32_pk_f32_fp4 decodes two codes.  Scale operands are 1.0.
+  g.s8 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(s, s, 0, false) & 0xffu;
+  g.s_round = ue4m3_to_f32(g.s8);
+  const float r = 1.0f / g.s_round;              // == (float)(1.0/(double)s8), tests/test_oracle_formats.py
+  const float S = (kVariant == ARCQ_VARIANT_G16) ? g.s_round : g.s_raw;   // reorder.cu:157 vs :474
+  uint32_t lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(lo, v[0] * r, v[1] * r, 1.0f, 0);
+  lo = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(lo, v[2] * r, v[3] * r, 1.0f, 1);
+  lo = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(lo, v[4] * r, v[5] * r, 1.0f, 2);
+  lo = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(lo, v[6] * r, v[7] * r, 1.0f, 3);
+  hi = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(hi, v[8] * r, v[9] * r, 1.0f, 0);
+  hi = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(hi, v[10] * r, v[11] * r, 1.0f, 1);
+  hi = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(hi, v[12] * r, v[13] * r, 1.0f, 2);
+  hi = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(hi, v[14] * r, v[15] * r, 1.0f, 3);
+  if (kResid) {
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const uint32_t w = b < 4 ? lo : hi;
+      f32x2 q2;
+      switch (b & 3) {
+        case 0: q2 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 1.0f, 0); break;
+        case 1: q2 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 1.0f, 1); break;
+        case 2: q2 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 1.0f, 2); break;
+        default: q2 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 1.0f, 3); break;
+      }
+      const float d0 = __builtin_fmaf(-q2.x, S, v[2 * b]);       // fused, oracle assumption A2
+      const float d1 = __builtin_fmaf(-q2.y, S, v[2 * b + 1]);
+      v[2 * b] = bf16_bits_to_f32(f32_to_bf16_bits(d0));
+      v[2 * b + 1] = bf16_bits_to_f32(f32_to_bf16_bits(d1));
+    }
+  }
+  g.packed = make_uint2(lo, hi);
+  return g;
+}
+
+}  // namespace arcq
