@@ -57,6 +57,10 @@ struct RowblockRegs {     // one tile pair of this lane: 2 x 16 bytes of codes, 
 
 constexpr int kRbWaves = 8, kRbThreads = kRbWaves * 64;
 
+// kUnits: image units (32 activations) per thread whose loads are issued up front (1, 2, 4 or 8)
+// (a ring of six pairs instead of three was measured on eight decode shapes, also those that leave a CU with a single
+//  workgroup: 0-15 % SLOWER everywhere -- the stream is not latency bound, the extra loads only delay the first tile)
+template <int kUnits>
 __global__ __launch_bounds__(kRbThreads, 4) void gemm_rowblock_kernel(RowblockParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const a_img = smem;                                        // [M][a_stride] fp16
@@ -72,13 +76,21 @@ __global__ __launch_bounds__(kRbThreads, 4) void gemm_rowblock_kernel(RowblockPa
   const int npairs = active ? pr_end - pr_begin : 0;
   const float alpha = p.alpha_host * (p.alpha_dev ? *p.alpha_dev : 1.0f);
 
-  // ---- this thread's first unit of the activation image is requested FIRST: a wave's loads return in order, so behind
-  //      the nine weight loads below it would only arrive with them (HBM latency) instead of at L2 latency
+  // ---- this thread's units of the activation image are requested FIRST: a wave's loads return in order, so behind
+  //      the nine weight loads below they would only arrive with them (HBM latency) instead of at L2 latency -- and a
+  //      thread with several units (large M * K) would pay that latency once per unit
   const int upr = p.pairs * 8, real = p.K >> 5;            // image units (32 elements) per token row: padded / real
   const int atoms_k = p.K >> 6;
-  const int m0 = min(tid / upr, p.M - 1), c0 = tid % upr, c0c = min(c0, real - 1);
-  const uint4 qv0 = *reinterpret_cast<const uint4*>(p.A + (size_t)m0 * (p.K >> 1) + c0c * 16);
-  const uint32_t sfw0 = *reinterpret_cast<const uint32_t*>(p.SFA + sf_atom_offset(m0, c0c >> 1, atoms_k));   // the atom's 4 bytes
+  const int units = p.M * upr;
+  uint4 qv_pre[kUnits];
+  uint32_t sf_pre[kUnits];
+#pragma unroll
+  for (int j = 0; j < kUnits; ++j) {
+    const int u = min(tid + j * kRbThreads, units - 1);
+    const int m = u / upr, c = min(u - m * upr, real - 1);
+    qv_pre[j] = *reinterpret_cast<const uint4*>(p.A + (size_t)m * (p.K >> 1) + c * 16);
+    sf_pre[j] = *reinterpret_cast<const uint32_t*>(p.SFA + sf_atom_offset(m, c >> 1, atoms_k));   // the atom's 4 bytes
+  }
 
   // ---- then the weight stream: three tile pairs per lane in flight
   const int rbc = active ? rb : 0;
@@ -99,24 +111,26 @@ __global__ __launch_bounds__(kRbThreads, 4) void gemm_rowblock_kernel(RowblockPa
   issue(r2);
 
   // ---- activation image: unit = 32 elements (16 packed bytes, two scale bytes) -> 64 bytes of fp16
-  {
-    for (int u = tid; u < p.M * upr; u += kRbThreads) {
-      const int m = u / upr, c = u - m * upr;
-      uint4 f0 = make_uint4(0, 0, 0, 0), f1 = f0, f2 = f0, f3 = f0;
-      if (c < real) {
-        uint4 qv = qv0;
-        uint32_t sf = sfw0;
-        if (u != tid) {                                     // second and later units of a thread (large M * K only)
-          qv = *reinterpret_cast<const uint4*>(p.A + (size_t)m * (p.K >> 1) + c * 16);
-          sf = *reinterpret_cast<const uint32_t*>(p.SFA + sf_atom_offset(m, c >> 1, atoms_k));
-        }
-        sf >>= (c & 1) * 16;
-        const f16x2 s0 = sf_pair_at(sf, 0), s1 = sf_pair_at(sf, 8);
-        f0 = dequant8(qv.x, s0).u; f1 = dequant8(qv.y, s0).u; f2 = dequant8(qv.z, s1).u; f3 = dequant8(qv.w, s1).u;
-      }
-      uint4* dst = reinterpret_cast<uint4*>(a_img + (size_t)m * p.a_stride + c * 64);
-      dst[0] = f0; dst[1] = f1; dst[2] = f2; dst[3] = f3;
+  auto put_unit = [&](int u, uint4 qv, uint32_t sf) __attribute__((always_inline)) {
+    const int m = u / upr, c = u - m * upr;
+    uint4 f0 = make_uint4(0, 0, 0, 0), f1 = f0, f2 = f0, f3 = f0;
+    if (c < real) {
+      sf >>= (c & 1) * 16;
+      const f16x2 s0 = sf_pair_at(sf, 0), s1 = sf_pair_at(sf, 8);
+      f0 = dequant8(qv.x, s0).u; f1 = dequant8(qv.y, s0).u; f2 = dequant8(qv.z, s1).u; f3 = dequant8(qv.w, s1).u;
     }
+    uint4* dst = reinterpret_cast<uint4*>(a_img + (size_t)m * p.a_stride + c * 64);
+    dst[0] = f0; dst[1] = f1; dst[2] = f2; dst[3] = f3;
+  };
+#pragma unroll
+  for (int j = 0; j < kUnits; ++j) {
+    const int u = tid + j * kRbThreads;
+    if (u < units) put_unit(u, qv_pre[j], sf_pre[j]);
+  }
+  for (int u = tid + kUnits * kRbThreads; u < units; u += kRbThreads) {       // beyond the prefetch (M * K > 128 K elements)
+    const int m = u / upr, c = min(u - m * upr, real - 1);
+    put_unit(u, *reinterpret_cast<const uint4*>(p.A + (size_t)m * (p.K >> 1) + c * 16),
+             *reinterpret_cast<const uint32_t*>(p.SFA + sf_atom_offset(m, c >> 1, atoms_k)));
   }
   __syncthreads();
 
@@ -209,15 +223,26 @@ int gemm_repacked(const GemmArgs& a, const uint8_t* RW, const uint8_t* RSF, hipS
   p.slices = s;
   p.pairs_per_slice = (p.pairs + s - 1) / s;
   const int lds = rowblock_lds_bytes(a.M, a.K, s, &p.a_stride);
-  static int lds_set = 0;
-  if (lds > 48 * 1024 && lds > lds_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rowblock_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_gemm_nvfp4_repacked: cannot reserve %d B of LDS: %s", lds, hipGetErrorString(e));
-    lds_set = lds;
-  }
+  const int units = a.M * p.pairs * 8;
+  const int per_thread = (units + kRbThreads - 1) / kRbThreads;
   const int bpw = kRbWaves / s;
   const int grid = (p.row_blocks + bpw - 1) / bpw;
-  hipLaunchKernelGGL(gemm_rowblock_kernel, dim3((unsigned)grid), dim3(kRbThreads), lds, stream, p);
+  auto launch = [&](auto kernel, int* lds_set) -> int {
+    if (lds > 48 * 1024 && lds > *lds_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_gemm_nvfp4_repacked: cannot reserve %d B of LDS: %s", lds, hipGetErrorString(e));
+      *lds_set = lds;
+    }
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(kRbThreads), lds, stream, p);
+    return ARCQ_OK;
+  };
+  static int lds_set[4] = {0, 0, 0, 0};
+  int rc;
+  if (per_thread <= 1) rc = launch(gemm_rowblock_kernel<1>, &lds_set[0]);
+  else if (per_thread <= 2) rc = launch(gemm_rowblock_kernel<2>, &lds_set[1]);
+  else if (per_thread <= 4) rc = launch(gemm_rowblock_kernel<4>, &lds_set[2]);
+  else rc = launch(gemm_rowblock_kernel<8>, &lds_set[3]);
+  if (rc != ARCQ_OK) return rc;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_gemm_nvfp4_repacked: launch failed: %s", hipGetErrorString(e));
   return ARCQ_OK;
