@@ -1,5 +1,6 @@
-// Per-group NVFP4 quantisation shared by the quantiser kernels (quantize.hip) and by the GEMM whose prologue quantises
-// its own activations (gemm_rowblock.hip): ONE statement of the arithmetic, so both produce the same bytes.
+// Per-group NVFP4 quantisation of the quantiser kernels (quantize.hip), kept apart from the row/launch logic: ONE
+// statement of the arithmetic for every kernel that has to produce the same bytes (a GEMM prologue that quantised its
+// own activations with it was bit-identical but slower).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
