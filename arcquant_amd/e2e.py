@@ -236,10 +236,85 @@ def bench_decode(name="qwen2.5-7b", batch=4, prefill=1024, steps=16, device="cud
             "hbm_floor_ms_at_8TBps": round((wb + kv) / 8e12 * 1e3, 4)}
 
 
+def bench_protocol(name="qwen2.5-7b", batch=4, prefill=1024, decode_steps=128, device="cuda:0", repeats=10, warmup=2, steps=4,
+                   fused=True, attention="cache", graph=True, layers=None):
+    """The reference's latency protocol (benchmarks/benchmark_e2e_arc.py): three timed modules -- prefill (:133-140), decode
+    for `decode_steps` steps over a GROWING cache (:142-155) and prefill + decode (:157-166) -- each run `warmup` times
+    untimed and `steps` times timed between two device synchronisations, repeated `repeats` times (:81-115); reported as
+    mean +- 1.96 sigma of the per-call milliseconds plus the peak device memory (:208-216).  graph=True replays the whole
+    multi-step decode (every step at its own cache length) from ONE HIP graph; graph=False issues it eagerly like the
+    reference does."""
+    cfg = dataclasses.replace(MODEL_CFGS[name])
+    if layers:
+        cfg.num_layers = layers
+    device = torch.device(device)
+
+    def module_benchmark(fn):
+        times, peaks = [], []
+        for _ in range(repeats):
+            for _ in range(warmup):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            torch.cuda.reset_peak_memory_stats()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+            peaks.append(torch.cuda.max_memory_allocated())
+            times.append((time.perf_counter() - t0) * 1e3 / steps)
+        t = torch.tensor(times, dtype=torch.float64)
+        return round(float(t.mean()), 3), round(1.96 * float(t.std(unbiased=False)), 3), max(peaks)
+
+    with torch.no_grad():
+        model = DecoderModel(cfg, batch, prefill + decode_steps, device, fused=fused, attention=attention)
+        tok = torch.randint(100, 200, (batch, prefill), device=device)
+        nxt = torch.full((batch, 1), 100, device=device, dtype=torch.int64)          # benchmark_e2e_arc.py:150
+
+        def run_prefill():
+            model.forward(tok, 0)
+
+        def decode_eager():
+            for i in range(decode_steps):
+                model.forward(nxt, prefill + i)
+
+        run_prefill()
+        decode_eager()
+        torch.cuda.synchronize()
+        run_decode = decode_eager
+        if graph:
+            g = torch.cuda.CUDAGraph()
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                with torch.cuda.graph(g, stream=st):
+                    decode_eager()
+            torch.cuda.synchronize()
+            run_decode = g.replay
+
+        def run_e2e():
+            run_prefill()
+            run_decode()
+
+        p_ms, p_ci, p_mem = module_benchmark(run_prefill)
+        d_ms, d_ci, d_mem = module_benchmark(run_decode)
+        e_ms, e_ci, e_mem = module_benchmark(run_e2e)
+    return {"protocol": "benchmark_e2e_arc.py: %d warm-up + %d timed calls x %d repeats, mean +- 1.96 sigma" % (warmup, steps, repeats),
+            "model": name, "layers": cfg.num_layers, "batch": batch, "prefill": prefill, "decode_steps": decode_steps, "fused": fused,
+            "attention": attention, "decode_from_hip_graph": bool(graph),
+            "prefill_ms": [p_ms, p_ci], "decode_ms": [d_ms, d_ci], "e2e_ms": [e_ms, e_ci],
+            "prefill_tok_per_s": round(batch * prefill / p_ms * 1e3, 0), "decode_tok_per_s": round(batch * decode_steps / d_ms * 1e3, 1),
+            "peak_memory_gb": round(max(p_mem, d_mem, e_mem) / 2 ** 30, 3)}
+
+
 if __name__ == "__main__":
     import json
     import sys
-    name = sys.argv[1] if len(sys.argv) > 1 else "qwen2.5-7b"
-    for fused, att in ((False, "current"), (True, "current"), (True, "cache")):
-        print(json.dumps(bench_decode(name, fused=fused, attention=att)))
-        torch.cuda.empty_cache()
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    name = args[0] if args else "qwen2.5-7b"
+    if "--protocol" in sys.argv:      # the reference's own benchmark protocol (growing cache, mean +- 1.96 sigma)
+        for graph in (True, False):
+            print(json.dumps(bench_protocol(name, graph=graph)), flush=True)
+            torch.cuda.empty_cache()
+    else:
+        for fused, att in ((False, "current"), (True, "current"), (True, "cache")):
+            print(json.dumps(bench_decode(name, fused=fused, attention=att)))
+            torch.cuda.empty_cache()

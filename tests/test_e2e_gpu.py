@@ -45,3 +45,19 @@ def test_bench_decode_reports_graph_and_eager_times():
     finally:
         del e2e.MODEL_CFGS["toy"]
     assert out["decode_tok_per_s"] > 0 and out["decode_ms_per_step_graph"] > 0 and out["layers"] == 2
+
+
+def test_reference_protocol_benchmark_runs_graph_and_eager():
+    """bench_protocol: the three modules of benchmarks/benchmark_e2e_arc.py (prefill, multi-step decode over a growing
+    cache, both) with its warm-up / timed / repeat counts; the graph and the eager decode run the same launches."""
+    e2e, cfg = _toy()
+    e2e.MODEL_CFGS["toy"] = cfg
+    try:
+        for graph in (True, False):
+            out = e2e.bench_protocol("toy", batch=2, prefill=16, decode_steps=3, repeats=2, warmup=1, steps=2, graph=graph)
+            assert out["decode_from_hip_graph"] is graph and out["decode_steps"] == 3
+            for key in ("prefill_ms", "decode_ms", "e2e_ms"):
+                assert out[key][0] > 0 and out[key][1] >= 0
+            assert out["e2e_ms"][0] > out["decode_ms"][0] * 0.5 and out["peak_memory_gb"] > 0
+    finally:
+        del e2e.MODEL_CFGS["toy"]
