@@ -107,6 +107,18 @@ __device__ __forceinline__ float rms_sumsq_tree(float* s, int bdx) {
 // quantiser 18 % (15.7 -> 18.5 us at 4096^2) and the dynamic one most of its time.
 enum : int { kDynNone = 0, kDynState = 1, kDynLocal = 2 };
 
+// LDS copy of a row (and of the norm weight): ONE PAD DWORD per 16-element group.  Unpadded, lane t of a wave gathers
+// element idx[16 t + j]; with reorder_index = identity (what the reference's own latency benchmark uses) that is byte
+// 32 t + 2 j -- the same bank for every 8th lane, an 8-way conflict on each of the 16 reads (measured: identity was SLOWER
+// than a random permutation, 47.2 vs 35.8 us at 8192^2).  With 36-byte groups the 64 lanes hit 64 different banks; a random
+// permutation is unaffected.  The pad is applied to a PAIR of int16 indices at once: e + 2 (e >> 4) <= 36861 fits 16 bits.
+__device__ __forceinline__ uint32_t lds_pad_pair(uint32_t w) { return w + (((w >> 4) & 0x0fff0fffu) << 1); }
+__device__ __forceinline__ void lds_store_chunk(uint16_t* row, int c, uint4 d) {       // chunk = 8 elements = half a group
+  uint32_t* p = reinterpret_cast<uint32_t*>(row) + 4 * c + (c >> 1);
+  p[0] = d.x; p[1] = d.y; p[2] = d.z; p[3] = d.w;
+}
+__host__ __device__ constexpr size_t lds_row_bytes(size_t KQ) { return KQ * 2 + KQ / 4; }
+
 template <int kVariant, int kMode, int kDyn, int kSilu>
 __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
     const uint16_t* __restrict__ X, const uint16_t* __restrict__ Xup, int64_t ldx, const uint16_t* __restrict__ Wn, float eps,
@@ -114,8 +126,8 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
     const unsigned int* __restrict__ dyn, int nslots, float* scale_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t* row_lds = reinterpret_cast<uint16_t*>(smem);
-  float* red = reinterpret_cast<float*>(smem + (size_t)KQ * 2);   // kModeRms only: 512 floats of reduction scratch ...
-  uint16_t* wn_lds = reinterpret_cast<uint16_t*>(smem + (size_t)KQ * 2 + 512 * sizeof(float));   // ... and the norm weights
+  float* red = reinterpret_cast<float*>(smem + lds_row_bytes(KQ));   // kModeRms only: 512 floats of reduction scratch ...
+  uint16_t* wn_lds = reinterpret_cast<uint16_t*>(smem + lds_row_bytes(KQ) + 512 * sizeof(float));   // ... and the norm weights
 
   const int tid = threadIdx.x;
   const int K = KQ + KE;
@@ -170,7 +182,7 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
     // the gather reads the norm weight of every channel: 16 scattered 2-byte global loads per group cost 2.6x
     // the whole static quantiser (41 vs 16 us at 4096^2), one LDS copy per workgroup does not
     for (int c = threadIdx.x; c < chunks; c += kQuantThreads)
-      *reinterpret_cast<uint4*>(wn_lds + (size_t)c * 8) = *reinterpret_cast<const uint4*>(Wn + (size_t)c * 8);
+      lds_store_chunk(wn_lds, c, *reinterpret_cast<const uint4*>(Wn + (size_t)c * 8));
     // visible after the barriers of the first row's reduction
   }
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
         for (int it = 0; it < 2; ++it) {
           const int c = it * bdx + v;
           uint4 d = *reinterpret_cast<const uint4*>(xrow + (size_t)c * 8);
-          *reinterpret_cast<uint4*>(row_lds + (size_t)c * 8) = d;
+          lds_store_chunk(row_lds, c, d);
           const uint32_t w4[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -204,10 +216,10 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
       } else if (kSilu) {
         const uint16_t* urow = Xup + (size_t)row * ldx;
         for (int c = tid; c < chunks; c += kQuantThreads)
-          *reinterpret_cast<uint4*>(row_lds + (size_t)c * 8) = silu_act_chunk<kSilu>(xrow, urow, c);
+          lds_store_chunk(row_lds, c, silu_act_chunk<kSilu>(xrow, urow, c));
       } else {
         for (int c = tid; c < chunks; c += kQuantThreads)
-          *reinterpret_cast<uint4*>(row_lds + (size_t)c * 8) = *reinterpret_cast<const uint4*>(xrow + (size_t)c * 8);
+          lds_store_chunk(row_lds, c, *reinterpret_cast<const uint4*>(xrow + (size_t)c * 8));
       }
       __syncthreads();
     }
@@ -222,22 +234,23 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const uint32_t ia = iw[j] & 0xffffu, ib = iw[j] >> 16;
+        const uint32_t pw = lds_pad_pair(iw[j]), pa = pw & 0xffffu, pb = pw >> 16;      // the same elements in the padded LDS rows
         float a, b;
         if (kSilu && gridDim.y > 1) {
           const uint16_t* urow = Xup + (size_t)row * ldx;
           a = bf16_bits_to_f32(silu_act_elem<kSilu>(xrow, urow, ia));
           b = bf16_bits_to_f32(silu_act_elem<kSilu>(xrow, urow, ib));
         } else {
-          a = bf16_bits_to_f32(row_lds[ia]);
-          b = bf16_bits_to_f32(row_lds[ib]);
+          a = bf16_bits_to_f32(row_lds[pa]);
+          b = bf16_bits_to_f32(row_lds[pb]);
         }
         if (kDyn != kDynNone) {                                 // torch: bf16(float(x) / scale)
           a = bf16_bits_to_f32(f32_to_bf16_bits(div_scale(a)));
           b = bf16_bits_to_f32(f32_to_bf16_bits(div_scale(b)));
         }
         if (kMode == kModeRms) {                                // rmsnorm.cu:165-171
-          a = bf16_bits_to_f32(f32_to_bf16_bits(a * bf16_bits_to_f32(wn_lds[ia]) * rstd));
-          b = bf16_bits_to_f32(f32_to_bf16_bits(b * bf16_bits_to_f32(wn_lds[ib]) * rstd));
+          a = bf16_bits_to_f32(f32_to_bf16_bits(a * bf16_bits_to_f32(wn_lds[pa]) * rstd));
+          b = bf16_bits_to_f32(f32_to_bf16_bits(b * bf16_bits_to_f32(wn_lds[pb]) * rstd));
         }
         v[2 * j] = a;
         v[2 * j + 1] = b;
@@ -376,7 +389,7 @@ static int launch_quantize(const void* X, const void* Wn, float eps, const int16
   if (!X || !idx || !Q || !SF || (kMode == kModeRms && !Wn)) return fail(ARCQ_ERR_NULL, "%s: NULL pointer", who);
   if (rows > INT32_MAX) return fail(ARCQ_ERR_UNSUPPORTED, "%s: too many rows", who);
 
-  size_t lds = (size_t)KQ * 2 + (kMode == kModeRms ? 512 * sizeof(float) + (size_t)KQ * 2 : 0);
+  size_t lds = lds_row_bytes((size_t)KQ) + (kMode == kModeRms ? 512 * sizeof(float) + lds_row_bytes((size_t)KQ) : 0);
   int grid, gsplit;
   quant_grid(rows, KQ, &grid, &gsplit);
   auto go = [&](auto kern) -> int {
