@@ -22,6 +22,12 @@ __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
   uint32_t r = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
   return ((u & 0x7fffffffu) > 0x7f800000u) ? ((u >> 16) | 0x40u) : r;
 }
+// x rounded to bf16 and widened again, through gfx950's v_cvt_pk_bf16_f32 (what the float -> __bf16 cast compiles to):
+// two instructions where the integer formulation above plus the shift back take eight.  The same function for all 2^32 bit
+// patterns, NaN stays NaN (tools/probe_bf16.hip, checked exhaustively on MI355X).  Used by the quantisers, which round
+// EVERY element (RMSNorm, dynamic scale, residual); the GEMM epilogues keep the integer form (a few conversions per
+// thread, and their register allocation is tuned around it).
+__device__ __forceinline__ float round_to_bf16(float f) { return (float)(__bf16)f; }
 
 // ue4m3 byte -> fp32.  (bits << 20) is the value scaled by 2^-120 (subnormals included); one multiply undoes it.
 __device__ __forceinline__ float ue4m3_to_f32(uint32_t b) { return __uint_as_float((b & 0x7fu) << 20) * 0x1p120f; }

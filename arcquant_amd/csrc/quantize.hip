@@ -74,23 +74,31 @@ __device__ __forceinline__ uint32_t absmax_bits_chunk(const uint4 d, uint32_t m)
 }
 
 // Sum of squares of one row in the reference's association order (rmsnorm.cu:113-154), so that the
-// fp32 result is bit-identical to the oracle's: virtual thread v in [0, KQ/16) owns the 16-byte
-// chunks v and KQ/16 + v, accumulates their 16 squares sequentially, then a fixed tree.
-// `s` is an LDS array of >= max(512, bdx) floats.  Returns the total in every thread.
-__device__ __forceinline__ float rms_sumsq_tree(float* s, int bdx) {
+// fp32 result is bit-identical to the oracle's: virtual thread v in [0, bdx = KQ/16) owns the 16-byte
+// chunks v and bdx + v and accumulates their 16 squares sequentially (the caller passes the partial sums of
+// v = tid and v = tid + 256); then the fixed tree s[v] += s[v + stride], stride = 256 ... 32, and a 32-lane shuffle.
+// The same tree with TWO barriers instead of seven: the stride-256 step adds two values this thread computed itself;
+// strides 128 and 64 only ever feed s[0..63], so wave 0 evaluates them for its 64 columns from four LDS reads;
+// stride 32 and below are shuffles.  `s` is an LDS array of >= 512 floats.  Returns the total in every thread.
+__device__ __forceinline__ float rms_sumsq_tree(float* s, int bdx, float p_lo, float p_hi) {
   const int tid = threadIdx.x;
-  __syncthreads();
-  for (int stride = 256; stride >= 32; stride >>= 1) {
-    for (int v = tid; v < stride && v < bdx; v += kQuantThreads)
-      if (v + stride < bdx) s[v] = s[v] + s[v + stride];
-    __syncthreads();
-  }
-  float val = (tid < 32 && tid < bdx) ? s[tid] : 0.0f;
+  const float s256 = (tid + 256 < bdx) ? p_lo + p_hi : p_lo;           // stride 256
+  if (tid < bdx) s[tid] = s256;
+  __syncthreads();                                                     // (also publishes the staged row)
+  if (tid < 64) {
+    const float x0 = s[tid], x1 = s[tid + 64], x2 = s[tid + 128], x3 = s[tid + 192];
+    const float y0 = (tid + 128 < bdx) ? x0 + x2 : x0;                 // stride 128: columns tid and tid + 64
+    const float y1 = (tid + 192 < bdx) ? x1 + x3 : x1;
+    float z = (tid + 64 < bdx) ? y0 + y1 : y0;                         // stride 64
+    const float up = __shfl_down(z, 32, 64);
+    if (tid < 32 && tid + 32 < bdx) z = z + up;                        // stride 32
+    float val = tid < 32 ? z : 0.0f;
 #pragma unroll
-  for (int sh = 16; sh > 0; sh >>= 1) val += __shfl_down(val, sh, 64);   // lane 0's cone = reference's
-  if (tid == 0) s[0] = val;
+    for (int sh = 16; sh > 0; sh >>= 1) val += __shfl_down(val, sh, 64);   // lane 0's cone = reference's
+    if (tid == 0) s[256] = val;
+  }
   __syncthreads();
-  return s[0];
+  return s[256];
 }
 
 // Per-tensor dynamic scale (kModeX only, arcq_quantize_x_dyn / arcq_silu_mul_quantize_x_dyn), selected by kDyn:
@@ -159,7 +167,7 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) scale_out[0] = dyn_scale;      // the caller's fp32 per-tensor scale
     // torch on the GPU divides a bf16 tensor by a 0-dim fp32 tensor in the COMMON dtype bf16: the scale operand is
     // rounded to bf16 at load (BinaryFunctor<BFloat16, BFloat16, BFloat16, DivFunctor>), the quotient is formed in fp32
-    dyn_scale = bf16_bits_to_f32(f32_to_bf16_bits(dyn_scale));
+    dyn_scale = round_to_bf16(dyn_scale);
   }
   // x / scale without ten instructions of IEEE division per element: q = x * r corrected by two FMAs (Markstein) and
   // the sign of x restored (-0 / s = -0).  With r = RN(1 / scale) this IS the correctly rounded quotient; checked
@@ -189,24 +197,29 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
     const uint16_t* xrow = X + (size_t)row * ldx;
     float rstd = 1.0f;
     if (kMode == kModeRms) {
-      for (int v = tid; v < bdx; v += kQuantThreads) {
-        float acc = 0.0f;
+      float part[2] = {0.0f, 0.0f};
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const int c = it * bdx + v;
-          uint4 d = *reinterpret_cast<const uint4*>(xrow + (size_t)c * 8);
-          lds_store_chunk(row_lds, c, d);
-          const uint32_t w4[4] = {d.x, d.y, d.z, d.w};
+      for (int k = 0; k < 2; ++k) {                              // bdx <= 512: virtual threads tid and tid + 256
+        const int v = tid + k * kQuantThreads;
+        if (v < bdx) {
+          float acc = 0.0f;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float a = bf16_bits_to_f32(w4[j] & 0xffffu), b = bf16_bits_to_f32(w4[j] >> 16);
-            acc = acc + a * a;
-            acc = acc + b * b;
+          for (int it = 0; it < 2; ++it) {
+            const int c = it * bdx + v;
+            uint4 d = *reinterpret_cast<const uint4*>(xrow + (size_t)c * 8);
+            lds_store_chunk(row_lds, c, d);
+            const uint32_t w4[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float a = bf16_bits_to_f32(w4[j] & 0xffffu), b = bf16_bits_to_f32(w4[j] >> 16);
+              acc = acc + a * a;
+              acc = acc + b * b;
+            }
           }
+          part[k] = acc;
         }
-        red[v] = acc;
       }
-      float sum = rms_sumsq_tree(red, bdx);
+      float sum = rms_sumsq_tree(red, bdx, part[0], part[1]);
       float var = sum / (float)KQ + eps;                       // rmsnorm.cu:157
       rstd = (float)(1.0 / sqrt((double)var));                 // oracle assumption A4
     } else {
@@ -245,12 +258,12 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
           b = bf16_bits_to_f32(row_lds[pb]);
         }
         if (kDyn != kDynNone) {                                 // torch: bf16(float(x) / scale)
-          a = bf16_bits_to_f32(f32_to_bf16_bits(div_scale(a)));
-          b = bf16_bits_to_f32(f32_to_bf16_bits(div_scale(b)));
+          a = round_to_bf16(div_scale(a));
+          b = round_to_bf16(div_scale(b));
         }
         if (kMode == kModeRms) {                                // rmsnorm.cu:165-171
-          a = bf16_bits_to_f32(f32_to_bf16_bits(a * bf16_bits_to_f32(wn_lds[pa]) * rstd));
-          b = bf16_bits_to_f32(f32_to_bf16_bits(b * bf16_bits_to_f32(wn_lds[pb]) * rstd));
+          a = round_to_bf16(a * bf16_bits_to_f32(wn_lds[pa]) * rstd);
+          b = round_to_bf16(b * bf16_bits_to_f32(wn_lds[pb]) * rstd);
         }
         v[2 * j] = a;
         v[2 * j + 1] = b;

@@ -59,8 +59,8 @@ __device__ __forceinline__ GroupQ quantize_group(float (&v)[16]) {
       }
       const float d0 = __builtin_fmaf(-q2.x, S, v[2 * b]);       // fused, oracle assumption A2
       const float d1 = __builtin_fmaf(-q2.y, S, v[2 * b + 1]);
-      v[2 * b] = bf16_bits_to_f32(f32_to_bf16_bits(d0));
-      v[2 * b + 1] = bf16_bits_to_f32(f32_to_bf16_bits(d1));
+      v[2 * b] = round_to_bf16(d0);
+      v[2 * b + 1] = round_to_bf16(d1);
     }
   }
   g.packed = make_uint2(lo, hi);
