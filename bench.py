@@ -114,10 +114,17 @@ def bench_extra(args, device, rank):
                 for f in launches:
                     f()
         torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         for _ in range(3):
             g.replay()
+        e1.record()
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # warm for ~40 ms of replays (the clock ramp after idle, see time_events_steady), then time >= reps replays / ~10 ms
+        per_replay_ms = max(e0.elapsed_time(e1) / 3, 1e-3)
+        for _ in range(min(20000, int(40.0 / per_replay_ms))):
+            g.replay()
+        reps = max(reps, min(20000, int(10.0 / per_replay_ms)))
         e0.record()
         for _ in range(reps):
             g.replay()
