@@ -359,7 +359,9 @@ def main():
                      "frac_of_fp4_peak": round(achieved / PEAK_FP4_TFLOPS, 4),
                      "note": "NVFP4 (ue4m3 scale per 16) has no exact mapping onto gfx950's E8M0-per-32 scaled fp4 MFMA; the exact "
                              "contraction runs on fp16 MFMA, so `peak` is the dense fp16/bf16 rate; frac_of_fp4_peak is the "
-                             "north-star denominator"},
+                             "north-star denominator.  Under sustained load the socket power limit sets the clock (this kernel "
+                             "~2.19 GHz, the fp16 library GEMM ~1.73 GHz at ~1.35 kW, profiles/r01f_clocks_power_under_load.txt): "
+                             "`peak` assumes 2.4 GHz, extra.gemm_4096.fp16_rocblas_TFLOPs is what the vendor GEMM sustains beside it"},
     }
     if rank == 0 and world == 1:
         if not args.no_cpu:
