@@ -268,8 +268,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     # default warm-up: ~55 ms of continuous load, past the power-management transient after idle (time_events_steady above;
-    # profiles/r01f_clock_transient.txt).  With W = 20 the timed steps sit inside it: 1200-1260 instead of ~1350 TFLOP/s.
+    # profiles/r01f_clock_transient.txt).  Timed steps inside that ramp read 1200-1260 instead of ~1350 TFLOP/s, so a caller's
+    # small --warmup is preceded by --prewarm-ms of the same untimed load.
     ap.add_argument("--warmup", type=int, default=500)
+    ap.add_argument("--prewarm-ms", type=float, default=60.0,
+                    help="continuous load (the same step) before the W warm-up steps, so that a small --warmup also measures sustained clocks")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     args = ap.parse_args()
@@ -308,6 +311,10 @@ def main():
     def step():
         agemm.matmul(p["qx"], p["qw"], p["sfx"], p["sfw"], p["alpha"], out=out)
 
+    if args.prewarm_ms > 0:                       # untimed: bring the clocks to their sustained state (see time_events_steady)
+        t_step = time_events(step, 5, 2)
+        for _ in range(min(5000, int(args.prewarm_ms * 1e3 / max(t_step, 1.0)))):
+            step()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -345,7 +352,7 @@ def main():
 
     result = {
         "metric": "ARC-NVFP4 GEMM TFLOP/s (M=4096, N=KQ=4096, KE=64)",
-        "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_ms": args.prewarm_ms,
         "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": "agemm.matmul on pre-quantised NVFP4 operands: M=4096 tokens x N=4096 (per rank) x K_aug=4160 "
