@@ -43,6 +43,8 @@ SYMBOLS = {
     "arcq_repacked_sf_bytes": (_i64, [_i64, _i64]),
     "arcq_gemm_repacked_supported": (_i32, [_i64, _i64, _i64]),
     "arcq_gemm_nvfp4_repacked": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _f32, _p, _p, _p, _i32, _p]),
+    "arcq_gemm_nvfp4_repacked_silu_absmax": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f32, _p, _p]),
+    "arcq_silu_mul_quantize_x_dyn_slots": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _i32, _p]),
 }
 
 _lib = None

@@ -193,7 +193,10 @@ def _quantize_dynamic(entry: str, who: str, X: torch.Tensor, KQ: int, reorder_in
     SFX = torch.empty((sf_buffer_bytes(M, K),), dtype=torch.uint8, device=dev)
     scale = torch.empty((1,), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        if slots is not None:
+        if slots is not None and layout is not None:
+            st = getattr(_lib.lib(), entry)(X.data_ptr(), reorder_index.data_ptr(), QX.data_ptr(), SFX.data_ptr(), scale.data_ptr(),
+                                            slots.data_ptr(), slots.numel(), M, KQ, KE, int(variant), int(layout), _stream(X))
+        elif slots is not None:
             st = getattr(_lib.lib(), entry)(X.data_ptr(), reorder_index.data_ptr(), QX.data_ptr(), SFX.data_ptr(), scale.data_ptr(),
                                             slots.data_ptr(), slots.numel(), M, KQ, KE, int(variant), _stream(X))
         elif layout is not None:
@@ -331,7 +334,7 @@ def reorder_quantize_x_dynamic(X: torch.Tensor, reorder_index: torch.Tensor, KE:
 GU_HALVES, GU_PAIRS = 0, 1
 
 
-def silu_mul_quantize_x_dynamic(GU: torch.Tensor, reorder_index: torch.Tensor, KE: int, variant=None, layout: int = GU_HALVES):
+def silu_mul_quantize_x_dynamic(GU: torch.Tensor, reorder_index: torch.Tensor, KE: int, variant=None, layout: int = GU_HALVES, absmax_slots=None):
     """Extension: the MLP's ``act_fn(gate) * up`` (model/qLlamaLayer.py:417, SiLU) folded into the dynamic quantiser.
     ``GU`` is [M, 2*KQ] bf16, the output of a fused gate_up projection: ``layout=GU_HALVES`` (gate | up) or ``GU_PAIRS``
     (g0, u0, g1, u1, ...: a weight with interleaved gate/up rows, as ``matmul_silu_mul`` takes).  Returns what
@@ -342,8 +345,49 @@ def silu_mul_quantize_x_dynamic(GU: torch.Tensor, reorder_index: torch.Tensor, K
         raise RuntimeError("Value error in silu_mul_quantize_x_dynamic: GU must hold gate and up halves of equal width")
     if layout not in (GU_HALVES, GU_PAIRS):
         raise RuntimeError("Value error in silu_mul_quantize_x_dynamic: layout must be GU_HALVES or GU_PAIRS")
+    if absmax_slots is not None:           # max |silu(gate) * up| words left by matmul_repacked_silu_absmax: ONE launch
+        if absmax_slots.dtype != torch.int32 or not absmax_slots.is_cuda or not absmax_slots.is_contiguous() or absmax_slots.numel() == 0:
+            raise RuntimeError("agemm.silu_mul_quantize_x_dynamic: absmax_slots must be a non-empty contiguous int32 GPU tensor")
+        return _quantize_dynamic("arcq_silu_mul_quantize_x_dyn_slots", "silu_mul_quantize_x_dynamic", GU, GU.shape[1] // 2, reorder_index, KE,
+                                 variant, slots=absmax_slots, layout=layout)
     return _quantize_dynamic("arcq_silu_mul_quantize_x_dyn", "silu_mul_quantize_x_dynamic", GU, GU.shape[1] // 2, reorder_index, KE,
                              variant, layout=layout)
+
+
+def matmul_repacked_silu_absmax(A: torch.Tensor, RW: torch.Tensor, SFA: torch.Tensor, RSF: torch.Tensor, scale, N: int, *, out=None,
+                                scale_host: float = 1.0):
+    """Extension for decode: ``matmul_repacked`` for a gate|up weight whose ROWS INTERLEAVE gate and up (g0, u0, g1, u1, ...).
+    Returns ``(y, absmax_slots)``: ``y`` bf16 [M, N] exactly as ``matmul_repacked`` returns it, and one int32 word per block of
+    16 weight rows holding max |silu(g) * u| of that block's outputs -- what ``silu_mul_quantize_x_dynamic(y, ...,
+    layout=GU_PAIRS, absmax_slots=...)`` needs to quantise ``act_fn(gate) * up`` (model/qLlamaLayer.py:417) in ONE launch."""
+    _need(A, torch.uint8, "A", 2)
+    _need(RW, torch.uint8, "RW", 1)
+    _need(SFA, torch.uint8, "SFA")
+    _need(RSF, torch.uint8, "RSF", 1)
+    M, K, N = A.shape[0], A.shape[1] * 2, int(N)
+    L = _lib.lib()
+    if K % 64 or N % 4 or RW.numel() != L.arcq_repacked_w_bytes(N, K) or RSF.numel() != L.arcq_repacked_sf_bytes(N, K):
+        raise RuntimeError(f"Value error in matmul_repacked_silu_absmax: RW / RSF do not belong to a [{N}, {K}] weight, or N % 4 != 0")
+    if SFA.numel() < L.arcq_sf_used_bytes(M, K):
+        raise RuntimeError("Value error in matmul_repacked_silu_absmax: SFA smaller than the swizzled layout of A")
+    if not L.arcq_gemm_repacked_supported(M, N, K):
+        raise RuntimeError(f"matmul_repacked_silu_absmax: M={M}, K={K} is outside the repacked path (see repacked_supported)")
+    alpha_host, alpha_dev = float(scale_host), None
+    if isinstance(scale, torch.Tensor) and scale.is_cuda and scale.dtype == torch.float32 and scale.numel() == 1:
+        alpha_dev = scale
+    else:
+        alpha_host *= float(scale)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
+    elif tuple(out.shape) != (M, N) or out.dtype != torch.bfloat16 or not out.is_contiguous():
+        raise RuntimeError("agemm.matmul_repacked_silu_absmax: out has the wrong shape / dtype")
+    slots = torch.empty(((N + 15) // 16,), dtype=torch.int32, device=A.device)
+    with torch.cuda.device(A.device):
+        st = L.arcq_gemm_nvfp4_repacked_silu_absmax(A.data_ptr(), RW.data_ptr(), SFA.data_ptr(), RSF.data_ptr(), out.data_ptr(),
+                                                    slots.data_ptr(), M, N, K, alpha_host,
+                                                    alpha_dev.data_ptr() if alpha_dev is not None else None, _stream(A))
+    _lib.check(st, "matmul_repacked_silu_absmax")
+    return out, slots
 
 
 # --- KV-cache functions of the reference module (bindings.cpp:576-581): OUT OF SCOPE (SURVEY.md row 12).

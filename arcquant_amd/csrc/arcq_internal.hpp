@@ -22,6 +22,8 @@ int quantize_x_dyn(const void* X, const int16_t* idx, uint8_t* QX, uint8_t* SFX,
                    int64_t KQ, int64_t KE, int variant, hipStream_t stream);
 int quantize_x_dyn_slots(const void* X, const int16_t* idx, uint8_t* QX, uint8_t* SFX, float* scale_out, const uint32_t* slots,
                          int64_t nslots, int64_t M, int64_t KQ, int64_t KE, int variant, hipStream_t stream);
+int silu_mul_quantize_x_dyn_slots(const void* GU, const int16_t* idx, uint8_t* QX, uint8_t* SFX, float* scale_out, const uint32_t* slots,
+                                  int64_t nslots, int64_t M, int64_t KQ, int64_t KE, int variant, int layout, hipStream_t stream);
 int silu_mul_quantize_x_dyn(const void* GU, const int16_t* idx, uint8_t* QX, uint8_t* SFX, float* scale_out, void* state, int64_t M,
                             int64_t KQ, int64_t KE, int variant, int layout, hipStream_t stream);
 

@@ -185,4 +185,32 @@ int arcq_gemm_nvfp4_repacked(const uint8_t* A, const uint8_t* RW, const uint8_t*
   return gemm_repacked(a, RW, RSF, (hipStream_t)stream);
 }
 
+int arcq_gemm_nvfp4_repacked_silu_absmax(const uint8_t* A, const uint8_t* RW, const uint8_t* SFA, const uint8_t* RSF, void* D,
+                                         uint32_t* absmax_slots, int64_t M, int64_t N, int64_t K, float alpha_host, const float* alpha_dev,
+                                         void* stream) {
+  const char* who = "arcq_gemm_nvfp4_repacked_silu_absmax";
+  if (M < 0 || N < 0 || K <= 0 || (K % 64) || (N % 4))
+    return fail(ARCQ_ERR_SHAPE, "%s: need M,N >= 0, K %% 64 == 0 and N %% 4 == 0 (M=%lld N=%lld K=%lld)", who, (long long)M, (long long)N, (long long)K);
+  if (M == 0 || N == 0) return ARCQ_OK;
+  if (!A || !RW || !SFA || !RSF || !D || !absmax_slots) return fail(ARCQ_ERR_NULL, "%s: NULL pointer", who);
+  if (N > INT32_MAX / 2 || K > INT32_MAX / 2) return fail(ARCQ_ERR_UNSUPPORTED, "%s: shape too large", who);
+  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(RW) | reinterpret_cast<uintptr_t>(D)) & 15)
+    return fail(ARCQ_ERR_SHAPE, "%s: A, RW and D must be 16-byte aligned", who);
+  if ((reinterpret_cast<uintptr_t>(SFA) | reinterpret_cast<uintptr_t>(RSF) | reinterpret_cast<uintptr_t>(absmax_slots)) & 3)
+    return fail(ARCQ_ERR_SHAPE, "%s: SFA, RSF and absmax_slots must be 4-byte aligned", who);
+  GemmArgs a;
+  a.A = A; a.B = nullptr; a.SFA = SFA; a.SFB = nullptr; a.D = D;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K;
+  a.alpha_host = alpha_host; a.alpha_dev = alpha_dev; a.bias = nullptr; a.residual = nullptr; a.out_dtype = ARCQ_OUT_BF16;
+  a.workspace = nullptr; a.workspace_bytes = 0;
+  a.epilogue = kEpiSiluMul; a.absmax_slots = absmax_slots;
+  return gemm_repacked(a, RW, RSF, (hipStream_t)stream);
+}
+
+int arcq_silu_mul_quantize_x_dyn_slots(const void* GU, const int16_t* reorder_index, uint8_t* QX, uint8_t* SFX, float* scale_out,
+                                       const uint32_t* absmax_slots, int64_t nslots, int64_t M, int64_t KQ, int64_t KE, int variant,
+                                       int layout, void* stream) {
+  return silu_mul_quantize_x_dyn_slots(GU, reorder_index, QX, SFX, scale_out, absmax_slots, nslots, M, KQ, KE, variant, layout, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -47,6 +47,7 @@ struct RowblockParams {
   int slices;             // waves that share one row block (1, 2, 4 or 8)
   int pairs_per_slice;
   int a_stride;           // bytes per token row of the LDS image
+  unsigned int* silu_slots;   // kSiluAbsmax: one word per row block, max |silu(gate) * up| of its outputs (bf16 bits)
 };
 
 typedef uint32_t rb_u32x4 __attribute__((ext_vector_type(4)));
@@ -60,7 +61,11 @@ constexpr int kRbWaves = 8, kRbThreads = kRbWaves * 64;
 // kUnits: image units (32 activations) per thread whose loads are issued up front (1, 2, 4 or 8)
 // (a ring of six pairs instead of three was measured on eight decode shapes, also those that leave a CU with a single
 //  workgroup: 0-15 % SLOWER everywhere -- the stream is not latency bound, the extra loads only delay the first tile)
-template <int kUnits>
+// kSiluAbsmax: the weight rows interleave gate and up (g0, u0, g1, u1, ...) and the caller quantises silu(gate) * up next
+//              with a per-tensor dynamic scale: besides D, every row block leaves max |silu(g) * u| of its outputs (computed
+//              from the very bf16 values it stores, with the quantiser's own silu_mul_bf16) in silu_slots[row block], which
+//              saves the quantiser its abs-max launch (~4 us + a graph-node gap per decoder layer).  Two exp per lane, once.
+template <int kUnits, bool kSiluAbsmax>
 __global__ __launch_bounds__(kRbThreads, 4) void gemm_rowblock_kernel(RowblockParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const a_img = smem;                                        // [M][a_stride] fp16
@@ -183,6 +188,17 @@ __global__ __launch_bounds__(kRbThreads, 4) void gemm_rowblock_kernel(RowblockPa
   }
   const int n0 = rb * 16 + 4 * q;
   if (active && rl < p.M && n0 < p.N) finish4<uint32_t>(p, alpha, rl, n0, sum);
+  if constexpr (kSiluAbsmax) {                              // N % 4 == 0, bf16 out, no bias / residual (checked by the launcher)
+    uint32_t m = 0;
+    if (active && rl < p.M && n0 < p.N) {
+      const uint32_t b0 = f32_to_bf16_bits(alpha * sum[0]), b1 = f32_to_bf16_bits(alpha * sum[1]);
+      const uint32_t b2 = f32_to_bf16_bits(alpha * sum[2]), b3 = f32_to_bf16_bits(alpha * sum[3]);
+      m = max(silu_mul_bf16(b0, b1) & 0x7fffu, silu_mul_bf16(b2, b3) & 0x7fffu);
+    }
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, sh, 64));
+    if (lane == 0 && active) p.silu_slots[rb] = m;
+  }
 }
 
 // Repacked sizes: rows padded to 16, K to 256.
@@ -205,12 +221,16 @@ int gemm_repacked_supported(int64_t M, int64_t N, int64_t K) {
 }
 
 int gemm_repacked(const GemmArgs& a, const uint8_t* RW, const uint8_t* RSF, hipStream_t stream) {
+  const bool silu = a.epilogue == kEpiSiluMul;              // here: D stays gate|up, absmax_slots gets max |silu(g) * u| per row block
+  if (silu && (!a.absmax_slots || (a.N % 4) || a.bias || a.residual || a.out_dtype != ARCQ_OUT_BF16))
+    return fail(ARCQ_ERR_SHAPE, "arcq_gemm_nvfp4_repacked_silu_absmax: needs absmax_slots, N %% 4 == 0, bf16 output, no bias / residual");
   if (!gemm_repacked_supported(a.M, a.N, a.K))
     return fail(ARCQ_ERR_UNSUPPORTED, "arcq_gemm_nvfp4_repacked: M=%d K=%d outside the repacked path (M <= 16, activation image <= 160 KB)", a.M, a.K);
   RowblockParams p;
   p.A = a.A; p.SFA = a.SFA; p.RW = RW; p.RSF = RSF; p.D = a.D;
   p.alpha_dev = a.alpha_dev; p.bias = a.bias; p.residual = a.residual;
   p.M = a.M; p.N = a.N; p.K = a.K; p.alpha_host = a.alpha_host; p.out_dtype = a.out_dtype;
+  p.silu_slots = a.absmax_slots;
   p.pairs = (int)rowblock_pairs(a.K);
   p.row_blocks = (a.N + 15) / 16;
   // waves per row block: split while that still leaves <= 2048 wave tasks (half the chip's wave slots) or >= 7 tile pairs
@@ -236,12 +256,19 @@ int gemm_repacked(const GemmArgs& a, const uint8_t* RW, const uint8_t* RSF, hipS
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(kRbThreads), lds, stream, p);
     return ARCQ_OK;
   };
-  static int lds_set[4] = {0, 0, 0, 0};
+  static int lds_set[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int rc;
-  if (per_thread <= 1) rc = launch(gemm_rowblock_kernel<1>, &lds_set[0]);
-  else if (per_thread <= 2) rc = launch(gemm_rowblock_kernel<2>, &lds_set[1]);
-  else if (per_thread <= 4) rc = launch(gemm_rowblock_kernel<4>, &lds_set[2]);
-  else rc = launch(gemm_rowblock_kernel<8>, &lds_set[3]);
+  if (silu) {
+    if (per_thread <= 1) rc = launch(gemm_rowblock_kernel<1, true>, &lds_set[4]);
+    else if (per_thread <= 2) rc = launch(gemm_rowblock_kernel<2, true>, &lds_set[5]);
+    else if (per_thread <= 4) rc = launch(gemm_rowblock_kernel<4, true>, &lds_set[6]);
+    else rc = launch(gemm_rowblock_kernel<8, true>, &lds_set[7]);
+  } else {
+    if (per_thread <= 1) rc = launch(gemm_rowblock_kernel<1, false>, &lds_set[0]);
+    else if (per_thread <= 2) rc = launch(gemm_rowblock_kernel<2, false>, &lds_set[1]);
+    else if (per_thread <= 4) rc = launch(gemm_rowblock_kernel<4, false>, &lds_set[2]);
+    else rc = launch(gemm_rowblock_kernel<8, false>, &lds_set[3]);
+  }
   if (rc != ARCQ_OK) return rc;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_gemm_nvfp4_repacked: launch failed: %s", hipGetErrorString(e));

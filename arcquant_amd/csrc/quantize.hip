@@ -504,6 +504,22 @@ int silu_mul_quantize_x_dyn(const void* GU, const int16_t* idx, uint8_t* QX, uin
   return launch_quantize<kModeX, kDynState, kSiluHalves>(G, nullptr, 0.f, idx, QX, SFX, M, KQ, KE, variant, stream, who, st, grid, scale_out, U, 2 * KQ);
 }
 
+// The abs-max words of silu(gate) * up were produced elsewhere (the repacked gate|up GEMM's epilogue): one launch.
+int silu_mul_quantize_x_dyn_slots(const void* GU, const int16_t* idx, uint8_t* QX, uint8_t* SFX, float* scale_out, const uint32_t* slots,
+                                  int64_t nslots, int64_t M, int64_t KQ, int64_t KE, int variant, int layout, hipStream_t stream) {
+  const char* who = "arcq_silu_mul_quantize_x_dyn_slots";
+  if (layout != ARCQ_GU_HALVES && layout != ARCQ_GU_PAIRS) return fail(ARCQ_ERR_SHAPE, "%s: unknown layout %d", who, layout);
+  if (!scale_out || !slots || nslots <= 0 || nslots > INT32_MAX) return fail(ARCQ_ERR_NULL, "%s: NULL scale_out / absmax_slots, or no slots", who);
+  const int rc = launch_quantize<kModeX>(GU, nullptr, 0.f, idx, QX, SFX, 0, KQ, KE, variant, stream, who);
+  if (rc != ARCQ_OK || M <= 0) return rc;
+  if (!GU || !idx || !QX || !SFX) return fail(ARCQ_ERR_NULL, "%s: NULL pointer", who);
+  if ((reinterpret_cast<uintptr_t>(GU) & 15) != 0) return fail(ARCQ_ERR_SHAPE, "%s: GU must be 16-byte aligned", who);
+  const uint16_t* G = reinterpret_cast<const uint16_t*>(GU);
+  if (layout == ARCQ_GU_PAIRS)
+    return launch_quantize<kModeX, kDynState, kSiluPairs>(G, nullptr, 0.f, idx, QX, SFX, M, KQ, KE, variant, stream, who, slots, (int)nslots, scale_out, G, 2 * KQ);
+  return launch_quantize<kModeX, kDynState, kSiluHalves>(G, nullptr, 0.f, idx, QX, SFX, M, KQ, KE, variant, stream, who, slots, (int)nslots, scale_out, G + KQ, 2 * KQ);
+}
+
 int absmax_scale(const void* X, int64_t n, float* scale_out, hipStream_t stream) {
   if (n < 0) return fail(ARCQ_ERR_SHAPE, "arcq_absmax_scale: n < 0");
   if (!scale_out || (n > 0 && !X)) return fail(ARCQ_ERR_NULL, "arcq_absmax_scale: NULL pointer");

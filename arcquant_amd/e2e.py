@@ -163,8 +163,14 @@ class DecoderModel:
                     act, slots = agemm.matmul_silu_mul(A, L["gateup"].W, SFA, L["gateup"].SFW, L["gateup"].scale)
                     qa, sfa, sa = agemm.reorder_quantize_x_dynamic(act, self.idx_i, cfg.select_num, absmax_slots=slots)
                 else:                   # decode: the exp-heavy epilogue would sit on the streaming kernel's critical path
-                    gu = L["gateup"].matmul(A, SFA, L["gateup"].scale)                                # measured 29.0 vs 22.8 us
-                    qa, sfa, sa = agemm.silu_mul_quantize_x_dynamic(gu, self.idx_i, cfg.select_num, layout=agemm.GU_PAIRS)
+                    G = L["gateup"]                                                                   # measured 29.0 vs 22.8 us
+                    if G.RW is not None and agemm.repacked_supported(A.shape[0], G.out_f, G.in_f + G.KE):
+                        # the repacked GEMM leaves max |silu(g) * u| per row block: the quantiser needs no abs-max launch
+                        gu, slots = agemm.matmul_repacked_silu_absmax(A, G.RW, SFA, G.RSF, G.scale, G.out_f)
+                        qa, sfa, sa = agemm.silu_mul_quantize_x_dynamic(gu, self.idx_i, cfg.select_num, layout=agemm.GU_PAIRS, absmax_slots=slots)
+                    else:
+                        gu = G.matmul(A, SFA, G.scale)
+                        qa, sfa, sa = agemm.silu_mul_quantize_x_dynamic(gu, self.idx_i, cfg.select_num, layout=agemm.GU_PAIRS)
                 hcur = L["down"].matmul(qa, sfa, sa, scale_host=L["down"].scale_f, residual=hcur)
             else:
                 gate = agemm.matmul(A, L["gate"].W, SFA, L["gate"].SFW, L["gate"].scale)

@@ -214,11 +214,15 @@ def bench_extra(args, device, rank):
     idx_h = torch.arange(3584, dtype=torch.int16, device=device)
     idx_i = torch.arange(18944, dtype=torch.int16, device=device)
     wn = torch.ones(3584, dtype=torch.bfloat16, device=device)
+    gu_slots = torch.full((2 * 18944 // 16,), 0x4000, dtype=torch.int32, device=device)     # any valid abs-max words: timing only
     extra["decode_quantisers_us_graph"] = {
         "rmsnorm_quantize_x_M4_KQ3584": round(graph_time([lambda: agemm.rmsnorm_quantize_x(xq, wn, 1e-6, idx_h, 64)] * 8), 2),
         "reorder_quantize_x_dynamic_M4_KQ3584": round(graph_time([lambda: agemm.reorder_quantize_x_dynamic(xq, idx_h, 64)] * 8), 2),
         "silu_mul_quantize_x_dynamic_M4_KQ18944": round(graph_time([lambda: agemm.silu_mul_quantize_x_dynamic(gu, idx_i, 64)] * 8), 2),
-        "note": "per call, HIP-graph replay; the SiLU*up variant is two launches, the others one"}
+        "silu_mul_quantize_x_dynamic_absmax_slots_M4_KQ18944": round(graph_time(
+            [lambda: agemm.silu_mul_quantize_x_dynamic(gu, idx_i, 64, layout=agemm.GU_PAIRS, absmax_slots=gu_slots)] * 8), 2),
+        "note": "per call, HIP-graph replay; the SiLU*up variant is two launches, the others one (absmax_slots: the abs-max words "
+                "come from the repacked gate|up GEMM's epilogue, matmul_repacked_silu_absmax)"}
     del xq, gu
     try:
         from arcquant_amd.e2e import bench_decode

@@ -166,6 +166,18 @@ int arcq_gemm_nvfp4_repacked(const uint8_t *A, const uint8_t *RW, const uint8_t 
                              int64_t M, int64_t N, int64_t K, float alpha_host, const float *alpha_dev,
                              const void *bias, const void *residual, int out_dtype, void *stream);
 
+/* The gate|up projection of a decode step on the repacked path, for weights whose ROWS INTERLEAVE gate and up (g0, u0, g1,
+ * u1, ...): D = bf16 [M, N] as arcq_gemm_nvfp4_repacked writes it, and absmax_slots[i], i < ceil(N / 16), = max |silu(g) * u|
+ * (bf16 bits, computed from the stored values with the quantiser's own rounding) over the outputs of row block i.
+ * arcq_silu_mul_quantize_x_dyn_slots then quantises act = silu(gate) * up (model/qLlamaLayer.py:417 -> :73-77) from D in ONE
+ * launch: the abs-max pass of arcq_silu_mul_quantize_x_dyn disappears, the bytes are identical.  N % 4 == 0. */
+int arcq_gemm_nvfp4_repacked_silu_absmax(const uint8_t *A, const uint8_t *RW, const uint8_t *SFA, const uint8_t *RSF, void *D,
+                                         uint32_t *absmax_slots, int64_t M, int64_t N, int64_t K, float alpha_host,
+                                         const float *alpha_dev, void *stream);
+int arcq_silu_mul_quantize_x_dyn_slots(const void *GU, const int16_t *reorder_index, uint8_t *QX, uint8_t *SFX,
+                                       float *scale_out, const uint32_t *absmax_slots, int64_t nslots, int64_t M,
+                                       int64_t KQ, int64_t KE, int variant, int layout, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -517,6 +517,43 @@ def test_repacked_weight_gemm_equals_the_reference_layout_gemm():
         ag.matmul_repacked(A, RW[:-1], SFA, RSF, alpha, N)
 
 
+def test_repacked_gateup_gemm_leaves_the_absmax_of_silu_mul_for_a_one_launch_quantiser():
+    """matmul_repacked_silu_absmax: y == matmul_repacked(...) bit for bit, max over its slots == max |silu(g) * u| of the
+    torch pipeline, and silu_mul_quantize_x_dynamic(y, GU_PAIRS, absmax_slots=...) returns the bytes and the scale of the
+    two-launch path (one to eight waves per row block, ragged N % 16, M = 1 ... 16)."""
+    import torch.nn.functional as F
+    ag = _agemm()
+    for (M, IT, KQ, KE) in [(4, 2560, 512, 64), (1, 18, 256, 0), (3, 136, 256, 64), (16, 1000, 1024, 64), (4, 18944, 3584, 64)]:
+        N = 2 * IT
+        g = torch.Generator().manual_seed(M + IT)
+        x, sx = prescale(outlier_activations(M, KQ, 5 + M))
+        w = ((torch.rand(N, KQ, generator=g) * 2 - 1.0)).to(torch.bfloat16)               # rows: g0, u0, g1, u1, ...
+        w, sw = prescale(w)
+        idx = random_perm(KQ, 6).to(DEV)
+        QX, SFX = ag.reorder_quantize_x(x.to(DEV), idx, KE)
+        QW, SFW = ag.reorder_quantize_w(w.to(DEV), idx, KE)
+        RW, RSF = ag.repack_w(QW, SFW)
+        alpha = float(sx * sw)
+        want_y = ag.matmul_repacked(QX, RW, SFX, RSF, alpha, N)
+        y, slots = ag.matmul_repacked_silu_absmax(QX, RW, SFX, RSF, alpha, N)
+        assert torch.equal(y, want_y) and slots.shape == ((N + 15) // 16,) and slots.dtype == torch.int32
+        act = F.silu(y[:, 0::2]) * y[:, 1::2]
+        amax_bits = int(act.abs().max().view(torch.int16).item()) & 0x7fff
+        assert int(slots.max().item()) == amax_bits, (M, IT, KQ)
+        idx_i = random_perm(IT, 9).to(DEV)
+        ke_i = 64 if IT % 64 == 0 else 0
+        if IT % 16 == 0 and (IT + ke_i) % 64 == 0:
+            q2, s2, sc2 = ag.silu_mul_quantize_x_dynamic(y, idx_i, ke_i, layout=ag.GU_PAIRS)
+            q1, s1, sc1 = ag.silu_mul_quantize_x_dynamic(y, idx_i, ke_i, layout=ag.GU_PAIRS, absmax_slots=slots)
+            assert torch.equal(q1, q2) and float(sc1) == float(sc2), (M, IT, KQ)
+            used = _used_sf_mask(M, IT + ke_i, s1.numel())
+            assert torch.equal(s1.cpu()[used], s2.cpu()[used])
+    with pytest.raises(RuntimeError):
+        ag.matmul_repacked_silu_absmax(QX, RW, SFX, RSF, alpha, N + 2)
+    with pytest.raises(RuntimeError):
+        ag.silu_mul_quantize_x_dynamic(y, idx_i, ke_i, layout=ag.GU_PAIRS, absmax_slots=slots.float())
+
+
 def test_silu_mul_gemm_epilogue_equals_the_unfused_steps():
     """matmul_silu_mul on row-interleaved gate/up weights == matmul, then torch's silu and mul, bit for bit; its abs-max
     slots give the dynamic quantiser the same scale and bytes as the abs-max pass (decode kernel, 64-row, 128x128 and
