@@ -80,8 +80,11 @@ def time_events_steady(fn, iters, warm_ms=60.0):
     raises the clocks, and a compute-bound kernel only reaches its sustained duration after ~30 ms of continuous load
     (tools/clock_transient.py: the 4096^2 GEMM runs 152 -> 116 -> 112 -> 107 -> 105 -> 103 us per launch over its first 300
     launches, the fp16 library GEMM 113 -> 99).  Used for both sides of every comparison."""
-    t = time_events(fn, 5, 2)
-    return time_events(fn, iters, max(5, int(warm_ms * 1e3 / max(t, 1.0))))
+    done_ms, chunk = 0.0, 20
+    while done_ms < warm_ms:                       # chunks timed by events: a cold first call cannot shorten the warm-up
+        done_ms += time_events(fn, chunk, 0) * chunk / 1e3
+        chunk = min(chunk * 2, 400)
+    return time_events(fn, iters, 5)
 
 
 def gemm_flops(M, N, K):
