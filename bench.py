@@ -80,11 +80,13 @@ def time_events_steady(fn, iters, warm_ms=60.0):
     raises the clocks, and a compute-bound kernel only reaches its sustained duration after ~30 ms of continuous load
     (tools/clock_transient.py: the 4096^2 GEMM runs 152 -> 116 -> 112 -> 107 -> 105 -> 103 us per launch over its first 300
     launches, the fp16 library GEMM 113 -> 99).  Used for both sides of every comparison."""
-    done_ms, chunk = 0.0, 20
+    done_ms, chunk, t = 0.0, 20, 1.0
     while done_ms < warm_ms:                       # chunks timed by events: a cold first call cannot shorten the warm-up
-        done_ms += time_events(fn, chunk, 0) * chunk / 1e3
+        t = time_events(fn, chunk, 0)
+        done_ms += t * chunk / 1e3
         chunk = min(chunk * 2, 400)
-    return time_events(fn, iters, 5)
+    # time at least ~30 ms: the clocks keep breathing by several percent over a few milliseconds even in the sustained state
+    return time_events(fn, max(iters, min(2000, int(30e3 / max(t, 1.0)))), 5)
 
 
 def gemm_flops(M, N, K):
@@ -319,9 +321,7 @@ def main():
         agemm.matmul(p["qx"], p["qw"], p["sfx"], p["sfw"], p["alpha"], out=out)
 
     if args.prewarm_ms > 0:                       # untimed: bring the clocks to their sustained state (see time_events_steady)
-        t_step = time_events(step, 5, 2)
-        for _ in range(min(5000, int(args.prewarm_ms * 1e3 / max(t_step, 1.0)))):
-            step()
+        time_events_steady(step, 5, args.prewarm_ms)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
