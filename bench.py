@@ -174,10 +174,12 @@ def bench_extra(args, device, rank):
     for S in (4096, 8192):
         q = make_problem(S, S, S, 64, device)
         Kq = S + 64
-        t = time_events_steady(lambda: agemm.matmul(q["qx"], q["qw"], q["sfx"], q["sfw"], q["alpha"]), 50)
+        # two sustained windows each, the faster one reported: the first window of a kernel that has not run yet can still
+        # sit in the power-management ramp after 60 ms (observed on the library GEMM: 117 us, then 96-97 us ever after)
+        t = min(time_events_steady(lambda: agemm.matmul(q["qx"], q["qw"], q["sfx"], q["sfw"], q["alpha"]), 50) for _ in range(2))
         a16 = torch.randn(S, Kq, dtype=torch.float16, device=device)
         b16 = torch.randn(S, Kq, dtype=torch.float16, device=device)
-        t16 = time_events_steady(lambda: torch.matmul(a16, b16.t()), 50)
+        t16 = min(time_events_steady(lambda: torch.matmul(a16, b16.t()), 50) for _ in range(2))
         extra[f"gemm_{S}"] = {"us": round(t, 2), "TFLOPs": round(gemm_flops(S, S, Kq) / t / 1e6, 1),
                               "fp16_rocblas_us": round(t16, 2), "fp16_rocblas_TFLOPs": round(gemm_flops(S, S, Kq) / t16 / 1e6, 1),
                               "speedup_vs_fp16_rocblas": round(t16 / t, 3)}
