@@ -10,6 +10,16 @@ namespace arcq {
 // Records a formatted message for arcq_last_error() (thread-local) and returns `code`.
 int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 
+// Opt-in to more than 48 KB of dynamic LDS for `kernel` on the CURRENT device.  The attribute is per device and per
+// kernel, and the driver call costs host time, so each launcher keeps one LdsOptIn per kernel instantiation: a small
+// per-device table of the largest size already granted (relaxed atomics: two threads racing both make the same,
+// idempotent driver call).  Returns ARCQ_OK or ARCQ_ERR_LAUNCH (message recorded).
+constexpr int kMaxDevices = 64;
+struct LdsOptIn {
+  int granted[kMaxDevices];     // zero-initialised (static storage)
+};
+int ensure_dynamic_lds(const void* kernel, LdsOptIn& cache, int bytes, const char* who);
+
 // quantize.hip
 int quantize_x(const void* X, const int16_t* idx, uint8_t* QX, uint8_t* SFX, int64_t M, int64_t KQ, int64_t KE, int variant,
                hipStream_t stream);

@@ -1,5 +1,6 @@
 // extern "C" entry points of libarcq_hip.so (declared in include/arcq.h): argument validation,
-// dispatch between the two GEMM kernels, error text.  No allocation, no synchronisation, no state.
+// dispatch between the GEMM kernels, error text.  No allocation, no synchronisation; the only state is the
+// per-device record of LDS opt-ins already made (ensure_dynamic_lds) and the thread-local error text.
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -18,6 +19,21 @@ int fail(int code, const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
+}
+
+int ensure_dynamic_lds(const void* kernel, LdsOptIn& cache, int bytes, const char* who) {
+  if (bytes <= 48 * 1024) return ARCQ_OK;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "%s: hipGetDevice failed", who);
+  const bool cached = dev >= 0 && dev < kMaxDevices;
+  if (cached && __atomic_load_n(&cache.granted[dev], __ATOMIC_RELAXED) >= bytes) return ARCQ_OK;
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "%s: cannot reserve %d B of LDS: %s", who, bytes, hipGetErrorString(e));
+  if (cached) {     // keep the maximum: a smaller request after a larger one must not shrink the record
+    int seen = __atomic_load_n(&cache.granted[dev], __ATOMIC_RELAXED);
+    while (seen < bytes && !__atomic_compare_exchange_n(&cache.granted[dev], &seen, bytes, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  }
+  return ARCQ_OK;
 }
 
 }  // namespace arcq

@@ -333,13 +333,10 @@ int64_t gemm_decode_workspace_bytes(int64_t M, int64_t N, int64_t K) {
 
 template <int kADw, int kEpi>
 static int launch_decode(const DecodeParams& p, int splitk, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_decode_kernel<kADw, kEpi>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       decode_lds_bytes(4 * kADw));
-    if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_gemm_nvfp4 (decode): cannot reserve LDS: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  static LdsOptIn lds_opt;             // per kernel instantiation, per device
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_decode_kernel<kADw, kEpi>), lds_opt, decode_lds_bytes(4 * kADw),
+                                  "arcq_gemm_nvfp4 (decode)"))
+    return rc;
   // persistent workgroups, each walks tiles blockIdx.x, +grid, ...: two 8-wave groups per CU while their LDS fits
   static const int forced_grid = getenv("ARCQ_DECODE_GRID") ? atoi(getenv("ARCQ_DECODE_GRID")) : 0;
   const int per_cu = 2 * decode_lds_bytes(p.M) <= 160 * 1024 ? 2 : 1;

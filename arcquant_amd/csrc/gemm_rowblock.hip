@@ -27,6 +27,7 @@
 
 #include "arcq_internal.hpp"
 #include "gemm_common.hpp"
+#include "rowblock_split.hpp"
 
 namespace arcq {
 
@@ -45,7 +46,6 @@ struct RowblockParams {
   int pairs;              // K_padded / 256: tile pairs per row block
   int row_blocks;         // ceil(N / 16)
   int slices;             // waves that share one row block (1, 2, 4 or 8)
-  int pairs_per_slice;
   int a_stride;           // bytes per token row of the LDS image
   unsigned int* silu_slots;   // kSiluAbsmax: one word per row block, max |silu(gate) * up| of its outputs (bf16 bits)
 };
@@ -77,8 +77,12 @@ __global__ __launch_bounds__(kRbThreads, 4) void gemm_rowblock_kernel(RowblockPa
   const int rb = blockIdx.x * bpw + wave / p.slices;
   const int slice = wave % p.slices;
   const bool active = rb < p.row_blocks;
-  const int pr_begin = min(slice * p.pairs_per_slice, p.pairs), pr_end = min(pr_begin + p.pairs_per_slice, p.pairs);
-  const int npairs = active ? pr_end - pr_begin : 0;
+  // balanced K split: slice s owns base (+1 for the first `extra` slices) consecutive tile pairs -- with the launcher's
+  // slices <= pairs no slice is empty (an empty slice used to address one pair past its row block: out of bounds behind
+  // the last one).  A forced slices > pairs leaves trailing slices with npairs == 0; their loads are clamped to pair 0.
+  int pr_begin, pr_count;
+  rowblock_slice_range(p.pairs, p.slices, slice, &pr_begin, &pr_count);
+  const int npairs = active ? pr_count : 0;
   const float alpha = p.alpha_host * (p.alpha_dev ? *p.alpha_dev : 1.0f);
 
   // ---- this thread's units of the activation image are requested FIRST: a wave's loads return in order, so behind
@@ -99,8 +103,9 @@ __global__ __launch_bounds__(kRbThreads, 4) void gemm_rowblock_kernel(RowblockPa
 
   // ---- then the weight stream: three tile pairs per lane in flight
   const int rbc = active ? rb : 0;
-  const uint8_t* wp = p.RW + ((size_t)rbc * p.pairs + pr_begin) * 2048 + lane * 16;
-  const uint8_t* sp = p.RSF + ((size_t)rbc * p.pairs + pr_begin) * 256 + lane * 4;
+  const int pr_load = rowblock_load_base(pr_begin, npairs);   // never past the row block's own pairs
+  const uint8_t* wp = p.RW + ((size_t)rbc * p.pairs + pr_load) * 2048 + lane * 16;
+  const uint8_t* sp = p.RSF + ((size_t)rbc * p.pairs + pr_load) * 256 + lane * 4;
   const int last = npairs > 0 ? npairs - 1 : 0;
   int issued = 0;
   auto issue = [&](RowblockRegs& r) __attribute__((always_inline)) {       // unpredicated; the cursor stops at the last pair
@@ -233,30 +238,21 @@ int gemm_repacked(const GemmArgs& a, const uint8_t* RW, const uint8_t* RSF, hipS
   p.silu_slots = a.absmax_slots;
   p.pairs = (int)rowblock_pairs(a.K);
   p.row_blocks = (a.N + 15) / 16;
-  // waves per row block: split while that still leaves <= 2048 wave tasks (half the chip's wave slots) or >= 7 tile pairs
-  // per wave.  Measured (tools/repacked_bench.py, us): N=37888 K=3648 S=1/2/4: 23.7 / 20.6 / 23.5; N=10752: 11.5 / 8.8 / 10.0;
-  // N=4096 K=4160: 10.7 / 7.8 / 6.4 / 6.1 (S=8).
   static const int forced = getenv("ARCQ_ROWBLOCK_SLICES") ? atoi(getenv("ARCQ_ROWBLOCK_SLICES")) : 0;   // tuning only
-  int s = 1;
-  while (s < 8 && p.pairs / (s * 2) >= 1 && ((int64_t)p.row_blocks * s * 2 <= 2048 || p.pairs / (s * 2) >= 7)) s *= 2;
+  int s = rowblock_choose_slices(p.row_blocks, p.pairs);
   if (forced == 1 || forced == 2 || forced == 4 || forced == 8) s = forced;
   p.slices = s;
-  p.pairs_per_slice = (p.pairs + s - 1) / s;
   const int lds = rowblock_lds_bytes(a.M, a.K, s, &p.a_stride);
   const int units = a.M * p.pairs * 8;
   const int per_thread = (units + kRbThreads - 1) / kRbThreads;
   const int bpw = kRbWaves / s;
   const int grid = (p.row_blocks + bpw - 1) / bpw;
-  auto launch = [&](auto kernel, int* lds_set) -> int {
-    if (lds > 48 * 1024 && lds > *lds_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_gemm_nvfp4_repacked: cannot reserve %d B of LDS: %s", lds, hipGetErrorString(e));
-      *lds_set = lds;
-    }
+  auto launch = [&](auto kernel, LdsOptIn* opt) -> int {
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), *opt, lds, "arcq_gemm_nvfp4_repacked")) return rc;
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(kRbThreads), lds, stream, p);
     return ARCQ_OK;
   };
-  static int lds_set[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  static LdsOptIn lds_set[8];           // one per kernel instantiation, each per device
   int rc;
   if (silu) {
     if (per_thread <= 1) rc = launch(gemm_rowblock_kernel<1, true>, &lds_set[4]);

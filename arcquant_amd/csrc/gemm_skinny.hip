@@ -307,13 +307,10 @@ template <int kWaves>
 static int launch_skinny(const SkinnyParams& p, int splitk, hipStream_t stream) {
   using C = SkinnyCfg<kWaves>;
   const int lds = C::lds_bytes(p.M);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel<kWaves>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       C::lds_bytes(kWaves == 16 ? 8 : 16));
-    if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_gemm_nvfp4 (skinny): cannot reserve LDS: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  static LdsOptIn lds_opt;             // per kernel instantiation, per device
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_skinny_kernel<kWaves>), lds_opt, C::lds_bytes(kWaves == 16 ? 8 : 16),
+                                  "arcq_gemm_nvfp4 (skinny)"))
+    return rc;
   // persistent workgroups, each walks tiles blockIdx.x, +grid, ...; 8-wave groups fit two per CU
   static const int forced_grid = getenv("ARCQ_SKINNY_GRID") ? atoi(getenv("ARCQ_SKINNY_GRID")) : 0;
   const int max_wg = forced_grid > 0 ? forced_grid : (kWaves == 16 ? 256 : 512);

@@ -433,12 +433,10 @@ static int launch_tile(const GemmArgs& a, hipStream_t stream, bool allow_split =
   auto kern = gemm_tile_kernel<BM, BN, WAVES_M, WAVES_N, kMfma32, kEpi, false, false>;
   if (kCanPipe && tile_pipe()) kern = gemm_tile_kernel<BM, BN, WAVES_M, WAVES_N, kMfma32, kEpi, false, kCanPipe>;
   else if (kCanStagger && tile_stagger()) kern = gemm_tile_kernel<BM, BN, WAVES_M, WAVES_N, kMfma32, kEpi, kCanStagger, false>;
-  static const void* attr_done = nullptr;       // per instantiation: the driver call costs host time on every launch otherwise
-  if (lds > 48 * 1024 && attr_done != reinterpret_cast<const void*>(kern)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_gemm_nvfp4 (tile): cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-    attr_done = reinterpret_cast<const void*>(kern);
-  }
+  // per instantiation and per (pipe, stagger) variant of it, per device: the driver call costs host time on every launch otherwise
+  static LdsOptIn lds_opt[3];
+  const int which = (kCanPipe && tile_pipe()) ? 1 : (kCanStagger && tile_stagger()) ? 2 : 0;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_opt[which], (int)lds, "arcq_gemm_nvfp4 (tile)")) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n * p.splits)), dim3(WAVES_M * WAVES_N * 64), lds, stream, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_gemm_nvfp4 (tile): launch failed: %s", hipGetErrorString(e));

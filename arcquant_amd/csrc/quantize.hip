@@ -386,14 +386,14 @@ static int launch_quantize(const void* X, const void* Wn, float eps, const int16
                            int64_t rows, int64_t KQ, int64_t KE, int variant, hipStream_t stream, const char* who,
                            const unsigned int* dyn = nullptr, int nslots = 0, float* scale_out = nullptr, const void* Xup = nullptr,
                            int64_t ldx = 0) {
-  if (rows < 0 || KQ <= 0 || (KQ % 16) || (KE % 16) || KE < 0 || KE > KQ || ((KQ + KE) % 64))
-    return fail(ARCQ_ERR_SHAPE, "%s: need KQ%%16==0, KE%%16==0, 0<=KE<=KQ, (KQ+KE)%%64==0 (rows=%lld KQ=%lld KE=%lld)", who,
+  // KQ and KE in whole scale-factor atoms (64 elements = 4 groups): every size the reference dispatches (bindings.cpp:141-160),
+  // every select_num it produces (multiples of 64) and every 64-aligned TP shard.  The kernel relies on it: the four
+  // lanes of a quad store the four scale bytes of one aligned dword of the swizzled layout.
+  if (rows < 0 || KQ <= 0 || (KQ % 64) || (KE % 64) || KE < 0 || KE > KQ)
+    return fail(ARCQ_ERR_SHAPE, "%s: need KQ%%64==0, KE%%64==0, 0<=KE<=KQ (rows=%lld KQ=%lld KE=%lld)", who,
                 (long long)rows, (long long)KQ, (long long)KE);
   if (variant != ARCQ_VARIANT_G16 && variant != ARCQ_VARIANT_G32)
     return fail(ARCQ_ERR_SHAPE, "%s: unknown variant %d", who, variant);
-  if (variant == ARCQ_VARIANT_G32 && ((KQ % 32) || (KE % 32)))
-    return fail(ARCQ_ERR_SHAPE, "%s: the G32 layout needs KQ%%32==0 and KE%%32==0 (KQ=%lld KE=%lld)", who, (long long)KQ,
-                (long long)KE);
   if (KQ > 32767)   // int16 reorder_index (bindings.cpp:137)
     return fail(ARCQ_ERR_UNSUPPORTED, "%s: KQ=%lld does not fit an int16 reorder_index", who, (long long)KQ);
   if (kMode == kModeRms && (KQ < 2048 || KQ > 8192))   // reduction tree of rmsnorm.cu:130-146 is defined for 128..512 threads
@@ -401,23 +401,26 @@ static int launch_quantize(const void* X, const void* Wn, float eps, const int16
   if (rows == 0) return ARCQ_OK;
   if (!X || !idx || !Q || !SF || (kMode == kModeRms && !Wn)) return fail(ARCQ_ERR_NULL, "%s: NULL pointer", who);
   if (rows > INT32_MAX) return fail(ARCQ_ERR_UNSUPPORTED, "%s: too many rows", who);
+  // 16-byte row / index loads, 8-byte code stores, 4-byte scale stores
+  if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(Xup)) & 15)
+    return fail(ARCQ_ERR_SHAPE, "%s: X and reorder_index must be 16-byte aligned", who);
+  if ((reinterpret_cast<uintptr_t>(Q) & 7) || (reinterpret_cast<uintptr_t>(SF) & 3))
+    return fail(ARCQ_ERR_SHAPE, "%s: the packed output must be 8-byte and the scale buffer 4-byte aligned", who);
 
   size_t lds = lds_row_bytes((size_t)KQ) + (kMode == kModeRms ? 512 * sizeof(float) + lds_row_bytes((size_t)KQ) : 0);
   int grid, gsplit;
   quant_grid(rows, KQ, &grid, &gsplit);
-  auto go = [&](auto kern) -> int {
-    if (lds > 48 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "%s: cannot reserve %zu B of LDS: %s", who, lds, hipGetErrorString(e));
-    }
+  auto go = [&](auto kern, LdsOptIn& opt) -> int {
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), opt, (int)lds, who)) return rc;
     hipLaunchKernelGGL(kern, dim3(grid, gsplit), dim3(kQuantThreads), lds, stream, (const uint16_t*)X, (const uint16_t*)Xup,
                        ldx ? ldx : KQ, (const uint16_t*)Wn, eps, idx, Q, SF, (int)rows, (int)KQ, (int)KE, dyn, nslots, scale_out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "%s: launch failed: %s", who, hipGetErrorString(e));
     return ARCQ_OK;
   };
-  if (variant == ARCQ_VARIANT_G16) return go(quantize_rows_kernel<ARCQ_VARIANT_G16, kMode, kDyn, kSilu>);
-  return go(quantize_rows_kernel<ARCQ_VARIANT_G32, kMode, kDyn, kSilu>);
+  static LdsOptIn lds_opt[2];           // per (kMode, kDyn, kSilu) instantiation and variant, each per device
+  if (variant == ARCQ_VARIANT_G16) return go(quantize_rows_kernel<ARCQ_VARIANT_G16, kMode, kDyn, kSilu>, lds_opt[0]);
+  return go(quantize_rows_kernel<ARCQ_VARIANT_G32, kMode, kDyn, kSilu>, lds_opt[1]);
 }
 
 int quantize_x(const void* X, const int16_t* idx, uint8_t* QX, uint8_t* SFX, int64_t M, int64_t KQ, int64_t KE, int variant,

@@ -2,7 +2,9 @@
  * arcq.h -- C-ABI of the MI355X-native (gfx950) ARC-NVFP4 hot path.
  *
  * This is the drop-in boundary: every entry point takes plain device pointers, sizes and a HIP
- * stream, allocates nothing, keeps no state, and returns an int status.  It replaces what the
+ * stream, allocates nothing and returns an int status.  The library holds no caller-visible state: scratch
+ * is caller-owned; internally it only remembers, per device, which kernels already have their large-LDS
+ * opt-in (thread-safe, any number of devices per process) and the calling thread's last error text.  It replaces what the
  * reference's pybind11 module `agemm` (kernels/src/bindings.cpp:551-575) reaches through
  * libtorch + CUTLASS.  Allocation of outputs stays in the host shim (arcquant_amd/agemm.py), with
  * the reference's sizes (bindings.cpp:83-95,110,133-134,181-182).
@@ -73,7 +75,8 @@ int64_t arcq_residual_pos(int64_t g, int64_t KQ, int64_t KE, int variant); /* -1
 /* agemm.reorder_quantize_x (bindings.cpp:122-163; kernels reorder.cu:68-203, 380-555, down.cu:71-233).
  *   X [M,KQ] bf16, reorder_index [KQ] int16 (a permutation of 0..KQ-1), QX [M,(KQ+KE)/2] u8,
  *   SFX >= arcq_sf_alloc_bytes(M, KQ+KE) bytes (only the offsets of rows < M are written).
- *   KQ % 16 == 0, KE % 16 == 0, 0 <= KE <= KQ, (KQ+KE) % 64 == 0; G32 also needs KQ % 32 == KE % 32 == 0. */
+ *   KQ % 64 == 0, KE % 64 == 0, 0 <= KE <= KQ <= 32767 (whole 64-element scale-factor atoms: every size the
+ *   reference dispatches and every select_num it produces).  X / reorder_index 16-byte, QX 8-byte, SFX 4-byte aligned. */
 int arcq_quantize_x(const void *X, const int16_t *reorder_index, uint8_t *QX, uint8_t *SFX, int64_t M, int64_t KQ,
                     int64_t KE, int variant, void *stream);
 
@@ -84,7 +87,10 @@ int arcq_quantize_w(const void *W, const int16_t *reorder_index, uint8_t *QW, ui
 
 /* agemm.rmsnorm_quantize_x (bindings.cpp:216-254; kernel rmsnorm.cu:68-255):
  *   xn = bf16(float(x) * float(w) * rsqrt(sum(x^2)/KQ + eps)) gathered by reorder_index, then as
- *   arcq_quantize_x.  2048 <= KQ <= 8192 (the reference's range).  The reference always uses the G16
+ *   arcq_quantize_x.  2048 <= KQ <= 8192 (the reference's range).  PARITY UNPINNED against the CUDA binary: the
+ *   reference's rsqrtf is a <= 2-ulp approximation, this kernel (and the oracle) use the correctly rounded
+ *   1/sqrt; the sum-of-squares association order and the fused residual multiply-add are restated from the kernel
+ *   text.  Byte-exact to that restatement (oracle/arcq_oracle.c), not provably to the reference's output.  The reference always uses the G16
  *   layout here; pass the variant the weights were quantised with (deviation D1). */
 int arcq_rmsnorm_quantize_x(const void *X, const void *W, float eps, const int16_t *reorder_index, uint8_t *QX,
                             uint8_t *SFX, int64_t M, int64_t KQ, int64_t KE, int variant, void *stream);

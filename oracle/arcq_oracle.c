@@ -11,9 +11,14 @@
  *      "parity unpinned" against the CUDA binary.  It is pinned as far as possible by
  *        (1) the e2m1 / e4m3 tables cross-checked against torch's float8_e4m3fn CPU conversion,
  *        (2) the reference's importable Python fake-quant path (kernels/fake.py,
- *            model/quantize.py), whose outputs are committed under tests/golden/ and must agree
- *            with the dequantised oracle output except on the documented tie / reciprocal /
- *            subnormal-scale cases.
+ *            model/quantize.py), whose outputs are committed under tests/golden/: with the
+ *            "fake semantics" switches below (ARCQ_SEM_*) this SAME group/row code reproduces those
+ *            outputs BIT FOR BIT (block partition, amax, /6, e2m1 grid, residual-channel selection,
+ *            dequantisation are thereby pinned to the reference's own outputs), and every element on
+ *            which the kernel-text semantics (flags = 0) differ is attributed by tests/test_oracle_pin.py
+ *            to exactly the switched rule that causes it: tie rule, x/s vs x*(1/s), scale grid, bf16
+ *            rounding of the residual.  What stays unpinned is only what the fake path does not have:
+ *            those four kernel-text rules themselves (A1-A3) and the rsqrt of the RMSNorm variant (A4).
  *
  * Every function cites the reference file:line it follows (paths under /root/reference).
  *
@@ -137,22 +142,73 @@ int64_t arcq_o_residual_pos(int64_t g, int64_t KQ, int64_t KE, int variant) {
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* semantics switches (TEST-ONLY: pin the shared code below to the reference's Python fake path) */
+/* ------------------------------------------------------------------------------------------ */
+#define ARCQ_SEM_TIE_FIRSTMIN 1  /* e2m1 by 15-way argmin, first minimum wins (kernels/fake.py:6-16) instead of RNE        */
+#define ARCQ_SEM_DIV_TRUE 2      /* x / s (kernels/fake.py:51) instead of x * (float)(1.0 / s) (reorder.cu:146,153)          */
+#define ARCQ_SEM_SCALE_FAKE 4    /* floor(log2)-rebuilt 3-bit-mantissa scale with a floor, no subnormals (fake.py:20-30)     */
+#define ARCQ_SEM_RESID_F32 8     /* residual x - q*s kept in fp32 (model/quantize.py:265 on an fp32 tensor), no bf16 rounding */
+
+typedef struct {
+  int flags;
+  float scale_floor; /* 1/512 in kernels/fake.py:21, 2e-3 in model/quantize.py:41 */
+  float log_eps;     /* 0 in kernels/fake.py:23, 1e-9 in model/quantize.py:43     */
+} Sem;
+static const Sem SEM_KERNEL = {0, 0.0f, 0.0f};
+
+/* quantize_e2m1 of the fake path (kernels/fake.py:6-16 == model/quantize.py:14-22): |t - g| in fp32 for the 15
+ * values in ascending order, first minimum.  Returns an e2m1 code; zero has no sign (the grid holds one 0.0). */
+static uint8_t fake_e2m1_encode(float t) {
+  static const float grid[15] = {-6.0f, -4.0f, -3.0f, -2.0f, -1.5f, -1.0f, -0.5f, 0.0f, 0.5f, 1.0f, 1.5f, 2.0f, 3.0f, 4.0f, 6.0f};
+  static const uint8_t code[15] = {15, 14, 13, 12, 11, 10, 9, 0, 1, 2, 3, 4, 5, 6, 7};
+  int best = 0;
+  float bd = fabsf(t - grid[0]);
+  for (int i = 1; i < 15; ++i) {
+    float d = fabsf(t - grid[i]);
+    if (d < bd) { bd = d; best = i; }
+  }
+  return code[best];
+}
+
+/* quantize_ue4m3 of the fake path (kernels/fake.py:20-30 / model/quantize.py:40-49), fp32 */
+static float fake_ue4m3(float s, const Sem *sem) {
+  s = s < sem->scale_floor ? sem->scale_floor : s;
+  s = s > FP8_MAX ? FP8_MAX : s;
+  float e = floorf(log2f(sem->log_eps != 0.0f ? s + sem->log_eps : s));
+  float p2 = exp2f(e);                     /* 2**exponent: exact */
+  float mant = s / p2 - 1.0f;
+  float qm = nearbyintf(mant * 8.0f) / 8.0f; /* torch.round: half to even */
+  return (1.0f + qm) * p2;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* one 16-element group                                                                        */
 /* ------------------------------------------------------------------------------------------ */
 
 /* amax -> (fp32 scale, ue4m3 byte, reciprocal) : reorder.cu:138,143,146 */
-static void group_scale(const float *v, float *scale, uint8_t *s8, float *rscale) {
+/* `sdec` = the scale the codes are divided by and dequantised with: the decoded ue4m3 byte, or -- under
+ * ARCQ_SEM_SCALE_FAKE -- the fake path's rebuilt scale, which need not be an e4m3 value (then *s8 = 0xff). */
+static void group_scale(const float *v, const Sem *sem, float *scale, uint8_t *s8, float *sdec, float *rscale) {
   float maxv = 0.0f;
   for (int i = 0; i < 16; ++i) {
     float a = fabsf(v[i]);
-    maxv = maxv > a ? maxv : a;          /* mymax, reorder.cu:53-63 */
+    maxv = maxv > a ? maxv : a;          /* mymax, reorder.cu:53-63 == torch.max(torch.abs(.)), fake.py:45 */
   }
-  float s = maxv / FP4_MAX;              /* A3 */
-  s = s < SCALE_EPS ? SCALE_EPS : s;     /* clamp(.., SCALE_EPS, FP8_MAX) reorder.cu:37,138 */
-  s = s > FP8_MAX ? FP8_MAX : s;
-  *scale = s;
-  *s8 = arcq_o_ue4m3_encode(s);
-  *rscale = (float)(1.0 / (double)arcq_o_ue4m3_decode(*s8)); /* `1.0 / float` is a double division */
+  float s = maxv / FP4_MAX;              /* A3; fake.py:46 */
+  if (sem->flags & ARCQ_SEM_SCALE_FAKE) {
+    if (s == 0.0f) s = 1e-9f;            /* fake.py:47 */
+    *scale = s;
+    *sdec = fake_ue4m3(s, sem);
+    uint8_t b = arcq_o_ue4m3_encode(*sdec);
+    *s8 = arcq_o_ue4m3_decode(b) == *sdec ? b : 0xff;
+  } else {
+    s = s < SCALE_EPS ? SCALE_EPS : s;   /* clamp(.., SCALE_EPS, FP8_MAX) reorder.cu:37,138 */
+    s = s > FP8_MAX ? FP8_MAX : s;
+    *scale = s;
+    *s8 = arcq_o_ue4m3_encode(s);
+    *sdec = arcq_o_ue4m3_decode(*s8);
+  }
+  *rscale = (float)(1.0 / (double)*sdec); /* `1.0 / float` is a double division */
 }
 
 static inline float clamp6(float x) { /* clamp(x,-6,6) via fpmax(a,fpmin(b,x)) reorder.cu:33-37 */
@@ -166,23 +222,29 @@ static void pack8(const uint8_t *codes, uint8_t *out) { /* PackFp4{low,high} reo
 
 /* Quantise 16 values (fp32 copies of bf16) -> 8 packed bytes + scale byte.  If resid != NULL also
  * emit the bf16-rounded residuals (as fp32) with S = rounded (G16) or un-rounded (G32) scale. */
-static void quant_group(const float *v, uint8_t *packed, uint8_t *s8_out, float *resid, int variant) {
-  float scale, rscale;
+static void quant_group(const float *v, const Sem *sem, uint8_t *packed, uint8_t *s8_out, float *sdec_out, float *resid,
+                        int variant) {
+  float scale, rscale, sdec;
   uint8_t s8;
-  group_scale(v, &scale, &s8, &rscale);
-  float S = variant == ARCQ_VARIANT_G16 ? arcq_o_ue4m3_decode(s8) : scale; /* reorder.cu:157 vs :474 */
+  group_scale(v, sem, &scale, &s8, &sdec, &rscale);
+  float S = variant == ARCQ_VARIANT_G16 ? sdec : scale; /* reorder.cu:157 vs :474 */
   uint8_t codes[16];
   for (int i = 0; i < 16; ++i) {
-    float r = clamp6(v[i] * rscale);                                 /* reorder.cu:153 */
-    codes[i] = arcq_o_e2m1_encode(r);
+    float t = (sem->flags & ARCQ_SEM_DIV_TRUE) ? v[i] / sdec : v[i] * rscale;   /* fake.py:51 | reorder.cu:153 */
+    codes[i] = (sem->flags & ARCQ_SEM_TIE_FIRSTMIN) ? fake_e2m1_encode(t) : arcq_o_e2m1_encode(clamp6(t));
     if (resid) {
       float q = arcq_o_e2m1_decode(codes[i]);
-      float d = fmaf(-q, S, v[i]);                                   /* reorder.cu:157, A2 */
-      resid[i] = arcq_o_bf16_to_f32(arcq_o_f32_to_bf16(d));
+      if (sem->flags & ARCQ_SEM_RESID_F32) {
+        resid[i] = v[i] - q * S;                                       /* x - q_x in fp32, model/quantize.py:265 */
+      } else {
+        float d = fmaf(-q, S, v[i]);                                   /* reorder.cu:157, A2 */
+        resid[i] = arcq_o_bf16_to_f32(arcq_o_f32_to_bf16(d));
+      }
     }
   }
   pack8(codes, packed);
   *s8_out = s8;
+  if (sdec_out) *sdec_out = sdec;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -190,27 +252,33 @@ static void quant_group(const float *v, uint8_t *packed, uint8_t *s8_out, float 
 /* ------------------------------------------------------------------------------------------ */
 
 /* One row that has already been gathered / normalised into fp32 copies of bf16 values. */
-static void quant_row(const float *xr, int64_t row, int64_t KQ, int64_t KE, int variant, int is_weight,
-                      uint8_t *q_row, uint8_t *SF) {
+/* SF (swizzled ue4m3 bytes, the product format) and/or sf_f32 (row-major [K/16] float scales of THIS row, by position:
+ * the only form that can hold a fake-path scale) receive the scales; either may be NULL. */
+static void quant_row(const float *xr, int64_t row, int64_t KQ, int64_t KE, int variant, int is_weight, const Sem *sem,
+                      uint8_t *q_row, uint8_t *SF, float *sf_f32) {
   int64_t K = KQ + KE, G = KQ / 16, P = (KQ - KE) / 16;
   for (int64_t g = 0; g < G; ++g) {
-    float resid[16];
+    float resid[16], sdec;
     uint8_t packed[8], s8;
     int has_res = g >= P;
-    quant_group(xr + 16 * g, packed, &s8, (has_res && !is_weight) ? resid : NULL, variant);
+    quant_group(xr + 16 * g, sem, packed, &s8, &sdec, (has_res && !is_weight) ? resid : NULL, variant);
     int64_t p = arcq_o_primary_pos(g, KQ, KE, variant);
     memcpy(q_row + 8 * p, packed, 8);
-    SF[arcq_o_sf_offset(row, p, K)] = s8;
+    if (SF) SF[arcq_o_sf_offset(row, p, K)] = s8;
+    if (sf_f32) sf_f32[p] = sdec;
     if (has_res) {
       int64_t pr = arcq_o_residual_pos(g, KQ, KE, variant);
       if (is_weight) {                       /* duplicate codes + scale: reorder.cu:306-316, 671-683 */
         memcpy(q_row + 8 * pr, packed, 8);
-        SF[arcq_o_sf_offset(row, pr, K)] = s8;
+        if (SF) SF[arcq_o_sf_offset(row, pr, K)] = s8;
+        if (sf_f32) sf_f32[pr] = sdec;
       } else {                               /* quantise the residual: reorder.cu:168-190, 502-541 */
         uint8_t rp[8], rs8;
-        quant_group(resid, rp, &rs8, NULL, variant);
+        float rdec;
+        quant_group(resid, sem, rp, &rs8, &rdec, NULL, variant);
         memcpy(q_row + 8 * pr, rp, 8);
-        SF[arcq_o_sf_offset(row, pr, K)] = rs8;
+        if (SF) SF[arcq_o_sf_offset(row, pr, K)] = rs8;
+        if (sf_f32) sf_f32[pr] = rdec;
       }
     }
   }
@@ -226,7 +294,7 @@ int arcq_o_quantize_x(const uint16_t *X, const int16_t *idx, int64_t M, int64_t 
   float *xr = (float *)malloc(sizeof(float) * (size_t)KQ);
   for (int64_t m = 0; m < M; ++m) {
     for (int64_t c = 0; c < KQ; ++c) xr[c] = arcq_o_bf16_to_f32(X[m * KQ + idx[c]]); /* reorder.cu:114-118 */
-    quant_row(xr, m, KQ, KE, variant, 0, QX + m * (KQ + KE) / 2, SFX);
+    quant_row(xr, m, KQ, KE, variant, 0, &SEM_KERNEL, QX + m * (KQ + KE) / 2, SFX, NULL);
   }
   free(xr);
   return 0;
@@ -240,9 +308,38 @@ int arcq_o_quantize_w(const uint16_t *W, const int16_t *idx, int64_t N, int64_t 
   float *xr = (float *)malloc(sizeof(float) * (size_t)KQ);
   for (int64_t n = 0; n < N; ++n) {
     for (int64_t c = 0; c < KQ; ++c) xr[c] = arcq_o_bf16_to_f32(W[n * KQ + idx[c]]);
-    quant_row(xr, n, KQ, KE, variant, 1, QW + n * (KQ + KE) / 2, SFW);
+    quant_row(xr, n, KQ, KE, variant, 1, &SEM_KERNEL, QW + n * (KQ + KE) / 2, SFW, NULL);
   }
   free(xr);
+  return 0;
+}
+
+/* TEST-ONLY twin of arcq_o_quantize_{x,w} with selectable semantics (ARCQ_SEM_*), for pinning the shared code above to
+ * the reference's Python fake path.  X is fp32 [rows, KQ] ALREADY in reordered channel order (the fake path
+ * quantises blocks of original channels, so only the identity permutation is element-comparable); outputs:
+ *   Q   [rows, K/2]  packed codes in the augmented-K layout (as the product format),
+ *   SFf [rows, K/16] float scale per group POSITION (row-major, not swizzled),
+ *   DQ  [rows, K]    decode(code) * scale by position -- what the fake path returns, for the G16 layout with the
+ *                    residual/duplicate groups gathered behind the primaries by the caller.
+ * flags = 0 reproduces arcq_o_quantize_{x,w} on bf16-representable input (tests assert this). */
+int arcq_o_quantize_sem(const float *X, int64_t rows, int64_t KQ, int64_t KE, int variant, int is_weight, int flags,
+                        float scale_floor, float log_eps, uint8_t *Q, float *SFf, float *DQ) {
+  if (KQ % 16 || KE % 16 || KE > KQ || KE < 0) return -1;
+  if (variant == ARCQ_VARIANT_G32 && (KQ % 32 || KE % 32)) return -1;
+  Sem sem = {flags, scale_floor, log_eps};
+  int64_t K = KQ + KE;
+  for (int64_t r = 0; r < rows; ++r) {
+    uint8_t *q = Q + r * (K / 2);
+    float *sf = SFf + r * (K / 16);
+    quant_row(X + r * KQ, r, KQ, KE, variant, is_weight, &sem, q, NULL, sf);
+    if (DQ)
+      for (int64_t p = 0; p < K / 16; ++p)
+        for (int i = 0; i < 16; ++i) {
+          uint8_t b = q[8 * p + i / 2];
+          uint8_t c = (i & 1) ? (uint8_t)(b >> 4) : (uint8_t)(b & 0xf);
+          DQ[r * K + 16 * p + i] = arcq_o_e2m1_decode(c) * sf[p];
+        }
+  }
   return 0;
 }
 
@@ -294,7 +391,7 @@ int arcq_o_rmsnorm_quantize_x(const uint16_t *X, const uint16_t *Wn, float eps, 
       float v = arcq_o_bf16_to_f32(x[i]) * arcq_o_bf16_to_f32(Wn[i]) * rstd; /* rmsnorm.cu:170 */
       xr[c] = arcq_o_bf16_to_f32(arcq_o_f32_to_bf16(v));
     }
-    quant_row(xr, m, KQ, KE, variant, 0, QX + m * (KQ + KE) / 2, SFX);
+    quant_row(xr, m, KQ, KE, variant, 0, &SEM_KERNEL, QX + m * (KQ + KE) / 2, SFX, NULL);
   }
   free(xr);
   return 0;

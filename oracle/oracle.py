@@ -67,6 +67,8 @@ def lib() -> ctypes.CDLL:
         L.arcq_o_quantize_w.argtypes = [p, p, i64, i64, i64, i32, p, p]
         L.arcq_o_rmsnorm_quantize_x.restype = i32
         L.arcq_o_rmsnorm_quantize_x.argtypes = [p, p, f32, p, i64, i64, i64, i32, p, p]
+        L.arcq_o_quantize_sem.restype = i32
+        L.arcq_o_quantize_sem.argtypes = [p, i64, i64, i64, i32, i32, i32, f32, f32, p, p, p]
         L.arcq_o_dequant.restype = None
         L.arcq_o_dequant.argtypes = [p, p, i64, i64, p]
         L.arcq_o_gemm.restype = i32
@@ -184,6 +186,41 @@ def rmsnorm_quantize_x(X_bits, Wn_bits, eps, idx, KE, variant=G16, sf_fill=SF_FI
     if rc:
         raise ValueError(f"oracle rmsnorm_quantize_x: bad shape M={M} KQ={KQ} KE={KE}")
     return QX, SFX
+
+
+# semantics switches of arcq_o_quantize_sem (TEST-ONLY; see the header of arcq_oracle.c)
+SEM_TIE_FIRSTMIN, SEM_DIV_TRUE, SEM_SCALE_FAKE, SEM_RESID_F32 = 1, 2, 4, 8
+SEM_KERNEL = 0                    # the kernel text: what arcq_o_quantize_{x,w} compute
+SEM_FAKE = 15                     # every rule as the reference's Python fake path has it
+FLOOR_KERNELS_FAKE = (1.0 / 512, 0.0)     # kernels/fake.py:21,23   (scale floor, log2 epsilon)
+FLOOR_MODEL_QUANTIZE = (2e-3, 1e-9)       # model/quantize.py:41,43
+
+
+def quantize_sem(X_f32, KE, variant=G16, is_weight=False, flags=SEM_KERNEL, floor=FLOOR_KERNELS_FAKE):
+    """arcq_o_quantize_sem: X fp32 [rows, KQ] already in reordered order -> (Q packed [rows,K/2], SFf fp32 [rows,K/16]
+    by group position, DQ fp32 [rows,K] by position).  flags=SEM_KERNEL equals quantize_{x,w} on bf16-valued input."""
+    X = _c(X_f32, np.float32)
+    rows, KQ = X.shape
+    K = KQ + KE
+    Q = np.zeros((rows, K // 2), np.uint8)
+    SFf = np.zeros((rows, K // 16), np.float32)
+    DQ = np.zeros((rows, K), np.float32)
+    rc = lib().arcq_o_quantize_sem(_ptr(X), rows, KQ, KE, variant, int(bool(is_weight)), int(flags), float(floor[0]), float(floor[1]),
+                                   _ptr(Q), _ptr(SFf), _ptr(DQ))
+    if rc:
+        raise ValueError(f"oracle quantize_sem: bad shape rows={rows} KQ={KQ} KE={KE} variant={variant}")
+    return Q, SFf, DQ
+
+
+def fake_layout(DQ, KQ, KE, variant=G16):
+    """Position-ordered [rows, KQ+KE] -> the fake path's [primaries in channel order | residual/duplicate groups in order]
+    (model/quantize.py:241,268) for an identity permutation."""
+    DQ = np.asarray(DQ)
+    prim = np.concatenate([DQ[:, 16 * primary_pos(g, KQ, KE, variant):][:, :16] for g in range(KQ // 16)], axis=1)
+    if not KE:
+        return prim
+    res = np.concatenate([DQ[:, 16 * residual_pos(g, KQ, KE, variant):][:, :16] for g in range((KQ - KE) // 16, KQ // 16)], axis=1)
+    return np.concatenate([prim, res], axis=1)
 
 
 def dequant(Q, SF, K=None):

@@ -107,6 +107,60 @@ def main():
         out[f"aw_KE{KE}"] = bits(aw)
     np.savez_compressed(os.path.join(HERE, "fake_arc_xw.npz"), **out)
 
+    # ---------------------------------------------------------------- fake ARC x / w at the headline size, IDENTITY permutation
+    # The exact pin of the kernel-text oracle (tests/test_oracle_pin.py).  With reorder_index = identity the fake path's
+    # 16-channel blocks are the kernel's groups, so outputs are comparable element by element.  The inputs are bf16 values
+    # already carrying the callers' per-tensor pre-scale with max(x) == 2688 exactly, so the scale the reference functions
+    # compute themselves (signed max / 2688) is exactly 1.0 and they quantise precisely these values.  They run in fp32
+    # (the kernels compute in fp32 on bf16 inputs) and, for the port, in bf16 (the dtype the reference's callers use).
+    out = {}
+    KQ, KE = 4096, 64
+    ident = torch.arange(KQ)
+
+    def prescaled(t):                       # t / (max|t| / 2688) in bf16, largest magnitude made positive
+        t = t.clone()
+        i = torch.argmax(t.abs())
+        t.view(-1)[i] = t.view(-1)[i].abs()
+        t = (t / (t.abs().max().float() / 2688.0)).to(torch.bfloat16)
+        assert float(t.max()) == 2688.0 and float(t.abs().max()) == 2688.0
+        return t
+
+    ties = torch.tensor([0.25, 0.75, 1.25, 1.75, 2.5, 3.5, 5.0, 6.0])
+
+    def engineer(t, g):                     # rows that force each rule the kernel text and the fake path disagree on
+        r0 = t.shape[0] - 4
+        # (1) exact e2m1 ties, both signs: block amax = 6 * 2^k so the block scale is exactly 2^k
+        for b, k in enumerate((-3, 0, 2, 5)):
+            for blk in (3 + 7 * b, KQ // 16 - 1 - b):          # a plain block and one inside the residual tail
+                v = torch.cat([ties, -ties]) * (2.0 ** k)
+                t[r0, 16 * blk:16 * blk + 16] = v[torch.randperm(16, generator=g)].to(torch.bfloat16)
+        # (2) block scales below 2^-6 (e4m3 subnormals in the kernel, finer grid in the fake path), below both floors, zero
+        t[r0 + 1] = (torch.rand(KQ, generator=g) * 0.09 * (torch.randint(0, 2, (KQ,), generator=g) * 2 - 1)).to(torch.bfloat16)
+        t[r0 + 1, 64:128] = (torch.rand(64, generator=g) * 0.011).to(torch.bfloat16)      # amax/6 < 2e-3
+        t[r0 + 1, 128:192] = (torch.rand(64, generator=g) * 0.004).to(torch.bfloat16)     # amax/6 < 1/512
+        t[r0 + 1, 192:208] = 0
+        t[r0 + 1, -32:-16] = (torch.rand(16, generator=g) * 0.011).to(torch.bfloat16)
+        t[r0 + 1, -16:] = 0
+        # (3) wide dynamic range inside blocks (many quotients near rounding boundaries)
+        t[r0 + 2] = (torch.randn(KQ, generator=g) * 300).clamp(-2600, 2600).to(torch.bfloat16)
+        t[r0 + 3] = (torch.randn(KQ, generator=g).exp() * 20 * (torch.randint(0, 2, (KQ,), generator=g) * 2 - 1)).clamp(-2600, 2600).to(torch.bfloat16)
+        t[0, 7] = 2688.0                    # the engineered rows may have replaced the tensor's maximum
+        return t
+
+    g = torch.Generator().manual_seed(4096)
+    x = engineer(prescaled(outlier_activations(12, KQ, 4096)), g)
+    w = engineer(prescaled((torch.rand(10, KQ, generator=g) * 3).to(torch.bfloat16)), g)
+    assert float(x.max()) == 2688.0 and float(w.max()) == 2688.0
+    for name, t, fn in (("x", x, quant.fake_reorder_quantize_x), ("w", w, quant.fake_reorder_quantize_w)):
+        q32, a32, s32 = fn(t.float().clone(), ident, KE)
+        q16, a16, s16 = fn(t.clone(), ident, KE)
+        assert float(s32) == 1.0 and float(s16) == 1.0
+        out[f"{name}_in"] = bits(t)
+        out[f"{name}_q_fp32"] = bits(q32)
+        out[f"{name}_q_bf16"] = bits(q16)
+    out["meta"] = np.array([KQ, KE], np.int64)
+    np.savez_compressed(os.path.join(HERE, "fake_arc_identity_4096.npz"), **out)
+
     # ---------------------------------------------------------------- oracle regression pins
     out = {}
     for tag, (M, KQ, KE, variant) in {

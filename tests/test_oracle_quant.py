@@ -54,27 +54,28 @@ def test_fake_port_matches_reference_arc_xw(golden, KE):
 
 
 # ---------------------------------------------------------------------------- kernel-text oracle vs reference fake path
-def test_oracle_dequant_agrees_with_reference_fake_path(golden):
-    """Identity reorder, KE=0: dequant(oracle quantise) vs reference fake output on the same bf16 tensor.
-    They differ only where the fake path's argmin tie rule / x/s division / floor-not-subnormal scale
-    differ from the kernel text; the rate must stay small and the mismatches must be such cases."""
+def test_oracle_dequant_differs_from_reference_fake_path_only_by_named_rules(golden):
+    """Identity reorder, KE=0, the small single-tensor fixture (kernels/fake.py flavour): dequant(oracle quantise) against the
+    fake path on the same bf16-valued tensor in fp32.  Every differing element must be covered by one of the three rule
+    differences (scale grid below 2^-6, reciprocal-multiply vs division, tie rule); the exact pin at the headline size,
+    residual channels included, is tests/test_oracle_pin.py.  (This replaces a statistical bound of < 1.2 % mismatches.)"""
+    from tests.test_oracle_pin import _causes_for_group_inputs
     g = golden("fake_nvfp4_tensor.npz")
-    t = from_bits(g["in_bf16"]).float()
-    # fp32 run of the reference (no bf16 intermediate rounding) is the fair comparison for the kernel math
-    want = _t(g["fake_fp32"], torch.float32).numpy()
     x32 = _t(g["in_fp32"], torch.float32)
     xb = bits(x32.to(torch.bfloat16))
     idx = np.arange(xb.shape[1], dtype=np.int16)
     q, sf = O.quantize_x(xb, idx, 0, O.G16)
     got = O.dequant(q, sf)
-    want_b = FQ.fake_nvfp4(from_bits(xb).float(), flavour=FQ.FLOOR_KERNELS_FAKE).numpy()
-    mism = got != want_b
-    rate = mism.mean()
-    assert rate < 0.012, rate
-    # every mismatch is within one e2m1 step of the block (no layout/indexing error hides here)
-    blk_scale = np.repeat(np.abs(want_b).reshape(-1, 16).max(1), 16).reshape(want_b.shape) / 6.0 + 1e-6
-    assert np.all(np.abs(got - want_b)[mism] <= 2.01 * blk_scale[mism])
-    assert want.shape == got.shape and t.shape == got.shape
+    want_b = FQ.fake_nvfp4(from_bits(xb).float(), flavour=FQ.FLOOR_KERNELS_FAKE).numpy()      # == reference (bit-checked above)
+    _, sff, dqf = O.quantize_sem(O.bf16_bits_to_f32(xb), 0, O.G16, flags=O.SEM_FAKE, floor=O.FLOOR_KERNELS_FAKE)
+    assert np.array_equal(dqf.view(np.uint32), want_b.view(np.uint32))
+    _, sfk, _ = O.quantize_sem(O.bf16_bits_to_f32(xb), 0, O.G16, flags=O.SEM_KERNEL)
+    v = O.bf16_bits_to_f32(xb).reshape(-1, 16)
+    S, D, T, sdiff = _causes_for_group_inputs(v, sfk.reshape(-1), sff.reshape(-1))
+    mism = (got != want_b).reshape(-1, 16)
+    assert mism.any()
+    assert not np.any(sdiff & ~S)
+    assert not np.any(mism & ~S[:, None] & ~D & ~T)
 
 
 @pytest.mark.parametrize("KE", [0, 64])
