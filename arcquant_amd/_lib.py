@@ -37,13 +37,18 @@ SYMBOLS = {
     "arcq_quantize_x_dyn": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p]),
     "arcq_silu_mul_quantize_x_dyn": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _i32, _p]),
     "arcq_gemm_silu_mul_slots": (_i64, [_i64, _i64, _i64]),
-    "arcq_gemm_nvfp4_silu_mul": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f32, _p, _p]),
+    "arcq_gemm_nvfp4_silu_mul": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f32, _p, _p, _p]),
     "arcq_quantize_x_dyn_slots": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _p]),
     "arcq_repacked_w_bytes": (_i64, [_i64, _i64]),
     "arcq_repacked_sf_bytes": (_i64, [_i64, _i64]),
     "arcq_gemm_repacked_supported": (_i32, [_i64, _i64, _i64]),
     "arcq_gemm_nvfp4_repacked": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _f32, _p, _p, _p, _i32, _p]),
+    "arcq_gemm_nvfp4_repacked_stream": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _f32, _p, _p, _p, _i32, _p]),
     "arcq_gemm_nvfp4_repacked_silu_absmax": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f32, _p, _p]),
+    "arcq_linear_fused_supported": (_i32, [_i32, _i64, _i64, _i64, _i64]),
+    "arcq_linear_rmsnorm_repacked": (_i32, [_p, _p, _f32, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _f32, _p, _p, _p, _i32, _p]),
+    "arcq_linear_rmsnorm_silu_repacked": (_i32, [_p, _p, _f32, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _f32, _p, _p, _p]),
+    "arcq_linear_dynamic_repacked": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i32, _f32, _p, _p, _i32, _p]),
     "arcq_silu_mul_quantize_x_dyn_slots": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _i32, _p]),
 }
 

@@ -247,7 +247,7 @@ def repacked_supported(M: int, N: int, K: int) -> bool:
 
 
 def matmul_repacked(A: torch.Tensor, RW: torch.Tensor, SFA: torch.Tensor, RSF: torch.Tensor, scale, N: int, *, bias=None, residual=None,
-                    out_dtype=torch.bfloat16, out=None, scale_host: float = 1.0):
+                    out_dtype=torch.bfloat16, out=None, scale_host: float = 1.0, kernel: str = "auto"):
     """``matmul`` for decode shapes over a weight prepared by ``repack_w`` (same arguments otherwise, plus the row count
     ``N`` of the weight): the kernel streams the weight in MFMA operand order with no LDS transpose and no barrier in its
     K loop.  Equals ``matmul`` on the un-repacked operands up to fp32 accumulation order."""
@@ -282,8 +282,11 @@ def matmul_repacked(A: torch.Tensor, RW: torch.Tensor, SFA: torch.Tensor, RSF: t
         _need(residual, torch.bfloat16, "residual", 2)
         if tuple(residual.shape) != (M, N):
             raise RuntimeError("agemm.matmul_repacked: residual must be [M, N]")
+    # kernel="stream": the kernel body of the fused decode linears (rmsnorm_matmul_repacked, dynamic_matmul_repacked), so that
+    # quantiser + this call is their bit-exact two-launch equivalent; "auto" = the fastest kernel for plain packed activations
+    fn = L.arcq_gemm_nvfp4_repacked_stream if kernel == "stream" else L.arcq_gemm_nvfp4_repacked
     with torch.cuda.device(A.device):
-        st = L.arcq_gemm_nvfp4_repacked(A.data_ptr(), RW.data_ptr(), SFA.data_ptr(), RSF.data_ptr(), out.data_ptr(), M, N, K, alpha_host,
+        st = fn(A.data_ptr(), RW.data_ptr(), SFA.data_ptr(), RSF.data_ptr(), out.data_ptr(), M, N, K, alpha_host,
                                         alpha_dev.data_ptr() if alpha_dev is not None else None,
                                         bias.data_ptr() if bias is not None else None,
                                         residual.data_ptr() if residual is not None else None,
@@ -292,7 +295,7 @@ def matmul_repacked(A: torch.Tensor, RW: torch.Tensor, SFA: torch.Tensor, RSF: t
     return out
 
 
-def matmul_silu_mul(A: torch.Tensor, B: torch.Tensor, SFA: torch.Tensor, SFB: torch.Tensor, scale, *, scale_host: float = 1.0):
+def matmul_silu_mul(A: torch.Tensor, B: torch.Tensor, SFA: torch.Tensor, SFB: torch.Tensor, scale, *, scale_host: float = 1.0, bias=None):
     """Extension: the gate|up GEMM with the MLP's ``act_fn(gate) * up`` (SiLU, model/qLlamaLayer.py:417) in
     its epilogue.  ``B`` is the quantised weight whose ROWS INTERLEAVE gate and up (g0, u0, g1, u1, ...).  Returns
     ``(act, absmax_slots)``: ``act`` bf16 [M, N/2] equals ``F.silu(y[:, 0::2]) * y[:, 1::2]`` of ``y = matmul(A, B, ...)``
@@ -316,7 +319,8 @@ def matmul_silu_mul(A: torch.Tensor, B: torch.Tensor, SFA: torch.Tensor, SFB: to
     slots = torch.empty((max(1, int(L.arcq_gemm_silu_mul_slots(M, N, K))),), dtype=torch.int32, device=A.device)
     with torch.cuda.device(A.device):
         st = L.arcq_gemm_nvfp4_silu_mul(A.data_ptr(), B.data_ptr(), SFA.data_ptr(), SFB.data_ptr(), act.data_ptr(), slots.data_ptr(), M, N, K,
-                                        alpha_host, alpha_dev.data_ptr() if alpha_dev is not None else None, _stream(A))
+                                        alpha_host, alpha_dev.data_ptr() if alpha_dev is not None else None,
+                                        _opt(bias, torch.bfloat16, "bias", (N,)), _stream(A))
     _lib.check(st, "matmul_silu_mul")
     return act, slots
 
@@ -390,6 +394,129 @@ def matmul_repacked_silu_absmax(A: torch.Tensor, RW: torch.Tensor, SFA: torch.Te
                                                     alpha_dev.data_ptr() if alpha_dev is not None else None, _stream(A))
     _lib.check(st, "matmul_repacked_silu_absmax")
     return out, slots
+
+
+SRC_RMSNORM, SRC_DYNAMIC = 1, 2
+
+
+def fused_supported(kind: int, M: int, N: int, KQ: int, KE: int) -> bool:
+    """Whether the fused decode linear (activation quantiser as the GEMM prologue) can run this shape: M <= 16 and the LDS
+    budget of one CU.  ``kind``: SRC_RMSNORM or SRC_DYNAMIC.  Callers fall back to the separate calls otherwise."""
+    return bool(_lib.lib().arcq_linear_fused_supported(int(kind), int(M), int(N), int(KQ), int(KE)))
+
+
+def _fused_common(who, X, reorder_index, RW, RSF, N, KE, variant):
+    _need(X, torch.bfloat16, "X", 2)
+    _need(reorder_index, torch.int16, "reorder_index", 1)
+    _need(RW, torch.uint8, "RW", 1)
+    _need(RSF, torch.uint8, "RSF", 1)
+    M, KQ = X.shape
+    KE, N = int(KE), int(N)
+    K = KQ + KE
+    L = _lib.lib()
+    if KQ % 64 or KE % 64 or KE < 0 or KE > KQ or reorder_index.numel() != KQ:
+        raise RuntimeError(f"Value error in {who}: KQ={KQ}, KE={KE} is not valid")
+    if RW.numel() != L.arcq_repacked_w_bytes(N, K) or RSF.numel() != L.arcq_repacked_sf_bytes(N, K):
+        raise RuntimeError(f"Value error in {who}: RW / RSF do not belong to a [{N}, {K}] weight")
+    if variant is None:
+        variant = variant_for_kq(KQ)
+    return M, KQ, KE, N, int(variant)
+
+
+def _opt(t, dtype, name, shape):
+    if t is None:
+        return None
+    _need(t, dtype, name, len(shape))
+    if tuple(t.shape) != tuple(shape):
+        raise RuntimeError(f"agemm: {name} must have shape {tuple(shape)}")
+    return t.data_ptr()
+
+
+def rmsnorm_matmul_repacked(X: torch.Tensor, W: torch.Tensor, eps: float, reorder_index: torch.Tensor, KE: int, RW: torch.Tensor,
+                            RSF: torch.Tensor, scale, N: int, *, bias=None, residual=None, out_dtype=torch.bfloat16, out=None,
+                            scale_host: float = 1.0, variant=None):
+    """Extension for decode: ``matmul_repacked(*rmsnorm_quantize_x(X, W, eps, reorder_index, KE), ...)`` in ONE launch -- the
+    RMSNorm + quantiser (benchmarks/modeling_arc.py:211-228) runs as the GEMM's prologue, once per CU.  Bit-identical to the
+    two calls.  ``W`` is the norm weight, ``scale`` the per-tensor weight scale (float or 0-dim device tensor)."""
+    M, KQ, KE, N, variant = _fused_common("rmsnorm_matmul_repacked", X, reorder_index, RW, RSF, N, KE, variant)
+    _need(W, torch.bfloat16, "W", 1)
+    if W.numel() != KQ or not fused_supported(SRC_RMSNORM, M, N, KQ, KE):
+        raise RuntimeError(f"rmsnorm_matmul_repacked: M={M}, KQ={KQ} outside the fused path (see fused_supported)")
+    alpha_host, alpha_dev = float(scale_host), None
+    if isinstance(scale, torch.Tensor) and scale.is_cuda and scale.dtype == torch.float32 and scale.numel() == 1:
+        alpha_dev = scale
+    else:
+        alpha_host *= float(scale)
+    if out_dtype not in (torch.bfloat16, torch.float32):
+        raise RuntimeError("agemm.rmsnorm_matmul_repacked: out_dtype must be bfloat16 or float32")
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=X.device)
+    elif tuple(out.shape) != (M, N) or out.dtype != out_dtype or not out.is_contiguous():
+        raise RuntimeError("agemm.rmsnorm_matmul_repacked: out has the wrong shape / dtype")
+    with torch.cuda.device(X.device):
+        st = _lib.lib().arcq_linear_rmsnorm_repacked(X.data_ptr(), W.data_ptr(), float(eps), reorder_index.data_ptr(), RW.data_ptr(), RSF.data_ptr(),
+                                                     out.data_ptr(), M, N, KQ, KE, variant, alpha_host,
+                                                     alpha_dev.data_ptr() if alpha_dev is not None else None,
+                                                     _opt(bias, torch.bfloat16, "bias", (N,)), _opt(residual, torch.bfloat16, "residual", (M, N)),
+                                                     OUT_BF16 if out_dtype == torch.bfloat16 else OUT_F32, _stream(X))
+    _lib.check(st, "rmsnorm_matmul_repacked")
+    return out
+
+
+def rmsnorm_matmul_repacked_silu(X: torch.Tensor, W: torch.Tensor, eps: float, reorder_index: torch.Tensor, KE: int, RW: torch.Tensor,
+                                 RSF: torch.Tensor, scale, N: int, *, scale_host: float = 1.0, variant=None, bias=None):
+    """Extension for decode, the MLP's first half in ONE launch: RMSNorm + quantise (prologue), gate|up GEMM over a repacked weight
+    whose ROWS INTERLEAVE gate and up, ``act_fn(gate) * up`` (SiLU, model/qLlamaLayer.py:417) in the epilogue.  Returns
+    ``(act bf16 [M, N/2], absmax_slots int32 [ceil(N/16)])``; ``act`` equals ``F.silu(y[:, 0::2]) * y[:, 1::2]`` of
+    ``y = rmsnorm_matmul_repacked(...)`` bit for bit and the slots let ``dynamic_matmul_repacked`` skip its abs-max pass."""
+    M, KQ, KE, N, variant = _fused_common("rmsnorm_matmul_repacked_silu", X, reorder_index, RW, RSF, N, KE, variant)
+    _need(W, torch.bfloat16, "W", 1)
+    if W.numel() != KQ or N % 4 or not fused_supported(SRC_RMSNORM, M, N, KQ, KE):
+        raise RuntimeError(f"rmsnorm_matmul_repacked_silu: M={M}, N={N}, KQ={KQ} outside the fused path (see fused_supported; N % 4 == 0)")
+    alpha_host, alpha_dev = float(scale_host), None
+    if isinstance(scale, torch.Tensor) and scale.is_cuda and scale.dtype == torch.float32 and scale.numel() == 1:
+        alpha_dev = scale
+    else:
+        alpha_host *= float(scale)
+    act = torch.empty((M, N // 2), dtype=torch.bfloat16, device=X.device)
+    slots = torch.empty(((N + 15) // 16,), dtype=torch.int32, device=X.device)
+    with torch.cuda.device(X.device):
+        st = _lib.lib().arcq_linear_rmsnorm_silu_repacked(X.data_ptr(), W.data_ptr(), float(eps), reorder_index.data_ptr(), RW.data_ptr(),
+                                                          RSF.data_ptr(), act.data_ptr(), slots.data_ptr(), M, N, KQ, KE, variant, alpha_host,
+                                                          alpha_dev.data_ptr() if alpha_dev is not None else None,
+                                                          _opt(bias, torch.bfloat16, "bias", (N,)), _stream(X))
+    _lib.check(st, "rmsnorm_matmul_repacked_silu")
+    return act, slots
+
+
+def dynamic_matmul_repacked(X: torch.Tensor, reorder_index: torch.Tensor, KE: int, RW: torch.Tensor, RSF: torch.Tensor, scale_w: float, N: int, *,
+                            absmax_slots=None, bias=None, residual=None, out_dtype=torch.bfloat16, out=None, variant=None):
+    """Extension for decode: ``NVFP4_reorder_quantize_x`` (model/qLlamaLayer.py:73-77) + ``QLinearLayer.forward``
+    (qLinearLayer.py:62-78) in ONE launch: scale = max|X|/2688 (from ``absmax_slots`` when the producing kernel left them, else
+    computed from X by every workgroup), X/scale quantised in the GEMM's prologue, alpha = scale * scale_w (a host float: the
+    weight's per-tensor scale).  Returns ``(y, scale)``; bit-identical to ``reorder_quantize_x_dynamic`` + ``matmul_repacked``."""
+    M, KQ, KE, N, variant = _fused_common("dynamic_matmul_repacked", X, reorder_index, RW, RSF, N, KE, variant)
+    if not fused_supported(SRC_DYNAMIC, M, N, KQ, KE):
+        raise RuntimeError(f"dynamic_matmul_repacked: M={M}, KQ={KQ} outside the fused path (see fused_supported)")
+    if out_dtype not in (torch.bfloat16, torch.float32):
+        raise RuntimeError("agemm.dynamic_matmul_repacked: out_dtype must be bfloat16 or float32")
+    if absmax_slots is not None and (absmax_slots.dtype != torch.int32 or not absmax_slots.is_cuda or not absmax_slots.is_contiguous()
+                                     or absmax_slots.numel() == 0):
+        raise RuntimeError("agemm.dynamic_matmul_repacked: absmax_slots must be a non-empty contiguous int32 GPU tensor")
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=X.device)
+    elif tuple(out.shape) != (M, N) or out.dtype != out_dtype or not out.is_contiguous():
+        raise RuntimeError("agemm.dynamic_matmul_repacked: out has the wrong shape / dtype")
+    scale = torch.empty((1,), dtype=torch.float32, device=X.device)
+    with torch.cuda.device(X.device):
+        st = _lib.lib().arcq_linear_dynamic_repacked(X.data_ptr(), reorder_index.data_ptr(), RW.data_ptr(), RSF.data_ptr(), out.data_ptr(),
+                                                     scale.data_ptr(), absmax_slots.data_ptr() if absmax_slots is not None else None,
+                                                     absmax_slots.numel() if absmax_slots is not None else 0, M, N, KQ, KE, variant,
+                                                     float(scale_w), _opt(bias, torch.bfloat16, "bias", (N,)),
+                                                     _opt(residual, torch.bfloat16, "residual", (M, N)),
+                                                     OUT_BF16 if out_dtype == torch.bfloat16 else OUT_F32, _stream(X))
+    _lib.check(st, "dynamic_matmul_repacked")
+    return out, scale.reshape(())
 
 
 # --- KV-cache functions of the reference module (bindings.cpp:576-581): OUT OF SCOPE (SURVEY.md row 12).

@@ -57,11 +57,36 @@ struct GemmArgs {
 };
 enum : int { kEpiPlain = 0, kEpiSiluMul = 1 };
 int64_t gemm_silu_slots(int64_t M, int64_t N, int64_t K);   // slots the silu-mul epilogue of this shape writes
-// gemm_rowblock.hip: decode GEMM over a weight repacked into MFMA-operand-order tiles (see arcq.h)
+// gemm_stream.hip: persistent decode GEMM over a weight repacked into MFMA-operand-order tiles (see arcq.h), optionally with
+// the activation quantiser as its prologue
 int64_t gemm_repacked_w_bytes(int64_t N, int64_t K);
 int64_t gemm_repacked_sf_bytes(int64_t N, int64_t K);
 int gemm_repacked_supported(int64_t M, int64_t N, int64_t K);
-int gemm_repacked(const GemmArgs& a, const uint8_t* RW, const uint8_t* RSF, hipStream_t stream);
+int gemm_repacked(const GemmArgs& a, const uint8_t* RW, const uint8_t* RSF, hipStream_t stream);          // gemm_rowblock.hip
+int gemm_repacked_stream(const GemmArgs& a, const uint8_t* RW, const uint8_t* RSF, hipStream_t stream);   // gemm_stream.hip (A-B)
+struct FusedArgs {
+  int kind;                   // ARCQ_SRC_RMSNORM | ARCQ_SRC_DYNAMIC
+  int silu_act;               // ARCQ_SRC_RMSNORM only: D = bf16 silu(gate) * up [M, N/2] of interleaved gate|up rows + out_slots
+  const uint16_t* X;          // bf16 [M, KQ]
+  const uint16_t* Wn;         // rmsnorm weight bf16 [KQ]
+  float eps;
+  const int16_t* idx;
+  const uint32_t* in_slots;   // ARCQ_SRC_DYNAMIC: abs-max words of X or NULL
+  int n_in_slots;
+  float* scale_out;           // ARCQ_SRC_DYNAMIC: max|X| / 2688
+  const uint8_t* RW;
+  const uint8_t* RSF;
+  void* D;
+  uint32_t* out_slots;
+  int M, N, KQ, KE, variant;
+  float alpha_host;
+  const float* alpha_dev;
+  const uint16_t* bias;
+  const uint16_t* residual;
+  int out_dtype;
+};
+int gemm_fused_supported(int kind, int64_t M, int64_t N, int64_t KQ, int64_t KE);
+int gemm_fused(const FusedArgs& f, hipStream_t stream);
 int64_t gemm_skinny_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int64_t gemm_tile_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int64_t gemm_tile_silu_slots(int64_t M, int64_t N, int64_t K);

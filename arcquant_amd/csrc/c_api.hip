@@ -147,7 +147,7 @@ int64_t arcq_gemm_silu_mul_slots(int64_t M, int64_t N, int64_t K) {
 }
 
 int arcq_gemm_nvfp4_silu_mul(const uint8_t* A, const uint8_t* B, const uint8_t* SFA, const uint8_t* SFB, void* ACT, uint32_t* absmax_slots,
-                             int64_t M, int64_t N, int64_t K, float alpha_host, const float* alpha_dev, void* stream) {
+                             int64_t M, int64_t N, int64_t K, float alpha_host, const float* alpha_dev, const void* bias, void* stream) {
   const char* who = "arcq_gemm_nvfp4_silu_mul";
   if (M < 0 || N < 0 || K <= 0 || (K % 64) || (N % 8))
     return fail(ARCQ_ERR_SHAPE, "%s: need M,N >= 0, K %% 64 == 0 and N %% 8 == 0 (M=%lld N=%lld K=%lld)", who, (long long)M, (long long)N,
@@ -163,9 +163,10 @@ int arcq_gemm_nvfp4_silu_mul(const uint8_t* A, const uint8_t* B, const uint8_t* 
   GemmArgs a;
   a.A = A; a.B = B; a.SFA = SFA; a.SFB = SFB; a.D = ACT;
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
-  a.alpha_host = alpha_host; a.alpha_dev = alpha_dev; a.bias = nullptr; a.residual = nullptr; a.out_dtype = ARCQ_OUT_BF16;
+  a.alpha_host = alpha_host; a.alpha_dev = alpha_dev; a.bias = (const uint16_t*)bias; a.residual = nullptr; a.out_dtype = ARCQ_OUT_BF16;
   a.workspace = nullptr; a.workspace_bytes = 0;
   a.epilogue = kEpiSiluMul; a.absmax_slots = absmax_slots;
+  if (bias && M <= kSkinnyMaxM) return fail(ARCQ_ERR_UNSUPPORTED, "%s: bias is supported by the tile kernel only (M > 16); decode uses arcq_linear_rmsnorm_silu_repacked", who);
   // the 16-row decode kernel has no fused epilogue: every M <= 16 shape takes the 32-row kernel here
   if (M <= kSkinnyMaxM) return gemm_decode(a, (hipStream_t)stream);
   return gemm_tile(a, (hipStream_t)stream);
@@ -180,10 +181,9 @@ int64_t arcq_repacked_w_bytes(int64_t N, int64_t K) { return (N > 0 && K > 0) ? 
 int64_t arcq_repacked_sf_bytes(int64_t N, int64_t K) { return (N > 0 && K > 0) ? gemm_repacked_sf_bytes(N, K) : 0; }
 int arcq_gemm_repacked_supported(int64_t M, int64_t N, int64_t K) { return gemm_repacked_supported(M, N, K); }
 
-int arcq_gemm_nvfp4_repacked(const uint8_t* A, const uint8_t* RW, const uint8_t* SFA, const uint8_t* RSF, void* D, int64_t M, int64_t N,
+static int gemm_repacked_entry(bool via_stream, const char* who, const uint8_t* A, const uint8_t* RW, const uint8_t* SFA, const uint8_t* RSF, void* D, int64_t M, int64_t N,
                              int64_t K, float alpha_host, const float* alpha_dev, const void* bias, const void* residual, int out_dtype,
                              void* stream) {
-  const char* who = "arcq_gemm_nvfp4_repacked";
   if (M < 0 || N < 0 || K <= 0 || (K % 64))
     return fail(ARCQ_ERR_SHAPE, "%s: need M,N >= 0 and K %% 64 == 0 (M=%lld N=%lld K=%lld)", who, (long long)M, (long long)N, (long long)K);
   if (out_dtype != ARCQ_OUT_BF16 && out_dtype != ARCQ_OUT_F32) return fail(ARCQ_ERR_SHAPE, "%s: bad out_dtype %d", who, out_dtype);
@@ -198,7 +198,18 @@ int arcq_gemm_nvfp4_repacked(const uint8_t* A, const uint8_t* RW, const uint8_t*
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.alpha_host = alpha_host; a.alpha_dev = alpha_dev; a.bias = (const uint16_t*)bias; a.residual = (const uint16_t*)residual; a.out_dtype = out_dtype;
   a.workspace = nullptr; a.workspace_bytes = 0;
-  return gemm_repacked(a, RW, RSF, (hipStream_t)stream);
+  return via_stream ? gemm_repacked_stream(a, RW, RSF, (hipStream_t)stream) : gemm_repacked(a, RW, RSF, (hipStream_t)stream);
+}
+
+int arcq_gemm_nvfp4_repacked(const uint8_t* A, const uint8_t* RW, const uint8_t* SFA, const uint8_t* RSF, void* D, int64_t M, int64_t N,
+                             int64_t K, float alpha_host, const float* alpha_dev, const void* bias, const void* residual, int out_dtype,
+                             void* stream) {
+  return gemm_repacked_entry(false, "arcq_gemm_nvfp4_repacked", A, RW, SFA, RSF, D, M, N, K, alpha_host, alpha_dev, bias, residual, out_dtype, stream);
+}
+int arcq_gemm_nvfp4_repacked_stream(const uint8_t* A, const uint8_t* RW, const uint8_t* SFA, const uint8_t* RSF, void* D, int64_t M, int64_t N,
+                                    int64_t K, float alpha_host, const float* alpha_dev, const void* bias, const void* residual, int out_dtype,
+                                    void* stream) {
+  return gemm_repacked_entry(true, "arcq_gemm_nvfp4_repacked_stream", A, RW, SFA, RSF, D, M, N, K, alpha_host, alpha_dev, bias, residual, out_dtype, stream);
 }
 
 int arcq_gemm_nvfp4_repacked_silu_absmax(const uint8_t* A, const uint8_t* RW, const uint8_t* SFA, const uint8_t* RSF, void* D,
@@ -221,6 +232,69 @@ int arcq_gemm_nvfp4_repacked_silu_absmax(const uint8_t* A, const uint8_t* RW, co
   a.workspace = nullptr; a.workspace_bytes = 0;
   a.epilogue = kEpiSiluMul; a.absmax_slots = absmax_slots;
   return gemm_repacked(a, RW, RSF, (hipStream_t)stream);
+}
+
+int arcq_linear_fused_supported(int kind, int64_t M, int64_t N, int64_t KQ, int64_t KE) { return gemm_fused_supported(kind, M, N, KQ, KE); }
+
+static int fused_common_checks(const char* who, const void* X, const int16_t* idx, const uint8_t* RW, const uint8_t* RSF, void* D, int64_t M,
+                               int64_t N, int64_t KQ, int64_t KE, int variant, int out_dtype) {
+  if (M < 0 || N < 0 || KQ <= 0 || (KQ % 64) || (KE % 64) || KE < 0 || KE > KQ)
+    return fail(ARCQ_ERR_SHAPE, "%s: need M,N >= 0, KQ%%64==0, KE%%64==0, 0<=KE<=KQ (M=%lld N=%lld KQ=%lld KE=%lld)", who, (long long)M,
+                (long long)N, (long long)KQ, (long long)KE);
+  if (variant != ARCQ_VARIANT_G16 && variant != ARCQ_VARIANT_G32) return fail(ARCQ_ERR_SHAPE, "%s: unknown variant %d", who, variant);
+  if (out_dtype != ARCQ_OUT_BF16 && out_dtype != ARCQ_OUT_F32) return fail(ARCQ_ERR_SHAPE, "%s: bad out_dtype %d", who, out_dtype);
+  if (M == 0 || N == 0) return 1;                              // nothing to do
+  if (!X || !idx || !RW || !RSF || !D) return fail(ARCQ_ERR_NULL, "%s: NULL pointer", who);
+  if (N > INT32_MAX / 2 || KQ > 32767) return fail(ARCQ_ERR_UNSUPPORTED, "%s: shape too large", who);
+  if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(RW) | reinterpret_cast<uintptr_t>(D)) & 15)
+    return fail(ARCQ_ERR_SHAPE, "%s: X, reorder_index, RW and D must be 16-byte aligned", who);
+  if (reinterpret_cast<uintptr_t>(RSF) & 3) return fail(ARCQ_ERR_SHAPE, "%s: RSF must be 4-byte aligned", who);
+  return ARCQ_OK;
+}
+
+int arcq_linear_rmsnorm_repacked(const void* X, const void* Wn, float eps, const int16_t* reorder_index, const uint8_t* RW, const uint8_t* RSF,
+                                 void* D, int64_t M, int64_t N, int64_t KQ, int64_t KE, int variant, float alpha_host, const float* alpha_dev,
+                                 const void* bias, const void* residual, int out_dtype, void* stream) {
+  const char* who = "arcq_linear_rmsnorm_repacked";
+  const int rc = fused_common_checks(who, X, reorder_index, RW, RSF, D, M, N, KQ, KE, variant, out_dtype);
+  if (rc != ARCQ_OK) return rc < 0 ? rc : ARCQ_OK;
+  if (!Wn || (reinterpret_cast<uintptr_t>(Wn) & 15)) return fail(Wn ? ARCQ_ERR_SHAPE : ARCQ_ERR_NULL, "%s: the norm weight must be a 16-byte aligned pointer", who);
+  FusedArgs f{};
+  f.kind = ARCQ_SRC_RMSNORM; f.X = (const uint16_t*)X; f.Wn = (const uint16_t*)Wn; f.eps = eps; f.idx = reorder_index;
+  f.RW = RW; f.RSF = RSF; f.D = D; f.M = (int)M; f.N = (int)N; f.KQ = (int)KQ; f.KE = (int)KE; f.variant = variant;
+  f.alpha_host = alpha_host; f.alpha_dev = alpha_dev; f.bias = (const uint16_t*)bias; f.residual = (const uint16_t*)residual; f.out_dtype = out_dtype;
+  return gemm_fused(f, (hipStream_t)stream);
+}
+
+int arcq_linear_rmsnorm_silu_repacked(const void* X, const void* Wn, float eps, const int16_t* reorder_index, const uint8_t* RW,
+                                      const uint8_t* RSF, void* ACT, uint32_t* absmax_slots, int64_t M, int64_t N, int64_t KQ, int64_t KE,
+                                      int variant, float alpha_host, const float* alpha_dev, const void* bias, void* stream) {
+  const char* who = "arcq_linear_rmsnorm_silu_repacked";
+  const int rc = fused_common_checks(who, X, reorder_index, RW, RSF, ACT, M, N, KQ, KE, variant, ARCQ_OUT_BF16);
+  if (rc != ARCQ_OK) return rc < 0 ? rc : ARCQ_OK;
+  if (N % 4) return fail(ARCQ_ERR_SHAPE, "%s: N %% 4 != 0 (interleaved gate|up rows)", who);
+  if (!Wn || !absmax_slots) return fail(ARCQ_ERR_NULL, "%s: NULL norm weight / absmax_slots", who);
+  if ((reinterpret_cast<uintptr_t>(Wn) & 15) || (reinterpret_cast<uintptr_t>(absmax_slots) & 3)) return fail(ARCQ_ERR_SHAPE, "%s: misaligned norm weight / absmax_slots", who);
+  FusedArgs f{};
+  f.kind = ARCQ_SRC_RMSNORM; f.silu_act = 1; f.X = (const uint16_t*)X; f.Wn = (const uint16_t*)Wn; f.eps = eps; f.idx = reorder_index;
+  f.RW = RW; f.RSF = RSF; f.D = ACT; f.out_slots = absmax_slots; f.M = (int)M; f.N = (int)N; f.KQ = (int)KQ; f.KE = (int)KE; f.variant = variant;
+  f.alpha_host = alpha_host; f.alpha_dev = alpha_dev; f.bias = (const uint16_t*)bias; f.out_dtype = ARCQ_OUT_BF16;
+  return gemm_fused(f, (hipStream_t)stream);
+}
+
+int arcq_linear_dynamic_repacked(const void* X, const int16_t* reorder_index, const uint8_t* RW, const uint8_t* RSF, void* D, float* scale_out,
+                                 const uint32_t* absmax_slots, int64_t nslots, int64_t M, int64_t N, int64_t KQ, int64_t KE, int variant,
+                                 float alpha_host, const void* bias, const void* residual, int out_dtype, void* stream) {
+  const char* who = "arcq_linear_dynamic_repacked";
+  const int rc = fused_common_checks(who, X, reorder_index, RW, RSF, D, M, N, KQ, KE, variant, out_dtype);
+  if (rc != ARCQ_OK) return rc < 0 ? rc : ARCQ_OK;
+  if (absmax_slots && (nslots <= 0 || nslots > INT32_MAX || (reinterpret_cast<uintptr_t>(absmax_slots) & 3)))
+    return fail(ARCQ_ERR_SHAPE, "%s: absmax_slots given but nslots = %lld, or misaligned", who, (long long)nslots);
+  FusedArgs f{};
+  f.kind = ARCQ_SRC_DYNAMIC; f.X = (const uint16_t*)X; f.idx = reorder_index; f.in_slots = absmax_slots; f.n_in_slots = absmax_slots ? (int)nslots : 0;
+  f.scale_out = scale_out; f.RW = RW; f.RSF = RSF; f.D = D; f.M = (int)M; f.N = (int)N; f.KQ = (int)KQ; f.KE = (int)KE; f.variant = variant;
+  f.alpha_host = alpha_host; f.bias = (const uint16_t*)bias; f.residual = (const uint16_t*)residual; f.out_dtype = out_dtype;
+  return gemm_fused(f, (hipStream_t)stream);
 }
 
 int arcq_silu_mul_quantize_x_dyn_slots(const void* GU, const int16_t* reorder_index, uint8_t* QX, uint8_t* SFX, float* scale_out,

@@ -102,7 +102,13 @@ __device__ __forceinline__ void finish4(const P& p, float alpha, int m, int n, c
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     d[r] = alpha * acc[r];                                          // epilogue in fp32 (nvfp4.cu:117-121)
-    if (p.bias && n + r < p.N) d[r] += bf16_bits_to_f32(p.bias[n + r]);
+    // bf16 output: every fused operand is added the way the reference's separate torch op adds it -- to the ROUNDED bf16
+    // result, rounding again: `y = matmul(...); y = y + bias` (qLinearLayer.py:74-76), then `x + y` in the decoder layer.
+    // fp32 output (row-parallel partials, tests) adds everything in fp32, one result.
+    if (p.bias && n + r < p.N) {
+      const float b = bf16_bits_to_f32(p.bias[n + r]);
+      d[r] = (p.out_dtype == ARCQ_OUT_F32 ? d[r] : bf16_bits_to_f32(f32_to_bf16_bits(d[r]))) + b;
+    }
     if (p.residual && n + r < p.N) {
       const float res = bf16_bits_to_f32(p.residual[(Idx)m * (Idx)p.N + (Idx)(n + r)]);
       d[r] = (p.out_dtype == ARCQ_OUT_F32 ? d[r] : bf16_bits_to_f32(f32_to_bf16_bits(d[r]))) + res;

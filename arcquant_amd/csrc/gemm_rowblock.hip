@@ -226,6 +226,8 @@ int gemm_repacked_supported(int64_t M, int64_t N, int64_t K) {
 }
 
 int gemm_repacked(const GemmArgs& a, const uint8_t* RW, const uint8_t* RSF, hipStream_t stream) {
+  static const int use_stream = getenv("ARCQ_REPACKED_STREAM") ? atoi(getenv("ARCQ_REPACKED_STREAM")) : 0;   // tuning / A-B only
+  if (use_stream) return gemm_repacked_stream(a, RW, RSF, stream);
   const bool silu = a.epilogue == kEpiSiluMul;              // here: D stays gate|up, absmax_slots gets max |silu(g) * u| per row block
   if (silu && (!a.absmax_slots || (a.N % 4) || a.bias || a.residual || a.out_dtype != ARCQ_OUT_BF16))
     return fail(ARCQ_ERR_SHAPE, "arcq_gemm_nvfp4_repacked_silu_absmax: needs absmax_slots, N %% 4 == 0, bf16 output, no bias / residual");

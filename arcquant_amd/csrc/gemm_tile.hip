@@ -320,8 +320,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
   auto store4 = [&](int m, int n, float d0, float d1, float d2, float d3) {
     if (m >= p.M || n >= p.N) return;
     if (kEpi == kEpiSiluMul) {                // columns n..n+3 = (gate_j, up_j, gate_j+1, up_j+1), j = n / 2; N % 4 == 0
-      const uint32_t a0 = silu_mul_bf16(f32_to_bf16_bits(alpha * d0), f32_to_bf16_bits(alpha * d1));
-      const uint32_t a1 = silu_mul_bf16(f32_to_bf16_bits(alpha * d2), f32_to_bf16_bits(alpha * d3));
+      uint32_t y[4] = {f32_to_bf16_bits(alpha * d0), f32_to_bf16_bits(alpha * d1), f32_to_bf16_bits(alpha * d2), f32_to_bf16_bits(alpha * d3)};
+      if (p.bias) {                             // `y = matmul(...); y = y + bias` of the separate GEMM, in bf16 (qLinearLayer.py:74-76)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = f32_to_bf16_bits(bf16_bits_to_f32(y[e]) + bf16_bits_to_f32(p.bias[n + e]));
+      }
+      const uint32_t a0 = silu_mul_bf16(y[0], y[1]);
+      const uint32_t a1 = silu_mul_bf16(y[2], y[3]);
       *reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(p.D) + (size_t)m * (p.N >> 1) + (n >> 1)) = a0 | (a1 << 16);
       act_max = max(act_max, max(a0 & 0x7fffu, a1 & 0x7fffu));
       return;
@@ -333,7 +338,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
     float d[4] = {alpha * d0, alpha * d1, alpha * d2, alpha * d3};
     if (p.bias) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) if (n + r < p.N) d[r] += bf16_bits_to_f32(p.bias[n + r]);
+      for (int r = 0; r < 4; ++r)
+        if (n + r < p.N) d[r] = (p.out_dtype == ARCQ_OUT_F32 ? d[r] : bf16_bits_to_f32(f32_to_bf16_bits(d[r]))) + bf16_bits_to_f32(p.bias[n + r]);
     }
     if (p.residual) {
 #pragma unroll

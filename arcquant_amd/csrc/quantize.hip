@@ -63,16 +63,6 @@ __device__ __forceinline__ uint32_t silu_act_elem(const uint16_t* g, const uint1
   return silu_mul_bf16(g[i], u[i]);
 }
 
-__device__ __forceinline__ uint32_t absmax_bits_chunk(const uint4 d, uint32_t m) {
-  const uint32_t w4[4] = {d.x, d.y, d.z, d.w};
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    m = max(m, w4[j] & 0x7fffu);
-    m = max(m, (w4[j] >> 16) & 0x7fffu);
-  }
-  return m;
-}
-
 // Sum of squares of one row in the reference's association order (rmsnorm.cu:113-154), so that the
 // fp32 result is bit-identical to the oracle's: virtual thread v in [0, bdx = KQ/16) owns the 16-byte
 // chunks v and bdx + v and accumulates their 16 squares sequentially (the caller passes the partial sums of
@@ -114,18 +104,6 @@ __device__ __forceinline__ float rms_sumsq_tree(float* s, int bdx, float p_lo, f
 // kDyn / kSilu are template parameters: as run-time branches inside the 16-element gather they cost the static
 // quantiser 18 % (15.7 -> 18.5 us at 4096^2) and the dynamic one most of its time.
 enum : int { kDynNone = 0, kDynState = 1, kDynLocal = 2 };
-
-// LDS copy of a row (and of the norm weight): ONE PAD DWORD per 16-element group.  Unpadded, lane t of a wave gathers
-// element idx[16 t + j]; with reorder_index = identity (what the reference's own latency benchmark uses) that is byte
-// 32 t + 2 j -- the same bank for every 8th lane, an 8-way conflict on each of the 16 reads (measured: identity was SLOWER
-// than a random permutation, 47.2 vs 35.8 us at 8192^2).  With 36-byte groups the 64 lanes hit 64 different banks; a random
-// permutation is unaffected.  The pad is applied to a PAIR of int16 indices at once: e + 2 (e >> 4) <= 36861 fits 16 bits.
-__device__ __forceinline__ uint32_t lds_pad_pair(uint32_t w) { return w + (((w >> 4) & 0x0fff0fffu) << 1); }
-__device__ __forceinline__ void lds_store_chunk(uint16_t* row, int c, uint4 d) {       // chunk = 8 elements = half a group
-  uint32_t* p = reinterpret_cast<uint32_t*>(row) + 4 * c + (c >> 1);
-  p[0] = d.x; p[1] = d.y; p[2] = d.z; p[3] = d.w;
-}
-__host__ __device__ constexpr size_t lds_row_bytes(size_t KQ) { return KQ * 2 + KQ / 4; }
 
 template <int kVariant, int kMode, int kDyn, int kSilu>
 __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
@@ -169,22 +147,8 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
     // rounded to bf16 at load (BinaryFunctor<BFloat16, BFloat16, BFloat16, DivFunctor>), the quotient is formed in fp32
     dyn_scale = round_to_bf16(dyn_scale);
   }
-  // x / scale without ten instructions of IEEE division per element: q = x * r corrected by two FMAs (Markstein) and
-  // the sign of x restored (-0 / s = -0).  With r = RN(1 / scale) this IS the correctly rounded quotient; checked
-  // EXHAUSTIVELY on MI355X for every finite bf16 x with |x| <= 4096 scale and every bf16 scale in 2^-100 .. 2^100
-  // (tools/probe_div.hip: 0 mismatches after the bf16 rounding; |x / scale| <= 2688 holds by construction).  Scales
-  // outside that range take the IEEE division.
-  const float dyn_rcp = 1.0f / dyn_scale;
-  const bool dyn_fast = kDyn != kDynNone && dyn_scale >= 0x1p-100f && dyn_scale <= 0x1p100f;
-  auto div_scale = [&](float x) -> float {
-    if (__builtin_expect(dyn_fast, 1)) {
-      float q = x * dyn_rcp;
-      const float e = __builtin_fmaf(-q, dyn_scale, x);
-      q = __builtin_fmaf(e, dyn_rcp, q);
-      return __builtin_copysignf(q, x);
-    }
-    return x / dyn_scale;
-  };
+  const DynDiv dyn_div(dyn_scale, kDyn != kDynNone);       // x / scale, bit-exact (quantize_device.hpp)
+  auto div_scale = [&](float x) -> float { return dyn_div(x); };
 
   if (kMode == kModeRms) {
     // the gather reads the norm weight of every channel: 16 scattered 2-byte global loads per group cost 2.6x

@@ -67,4 +67,49 @@ __device__ __forceinline__ GroupQ quantize_group(float (&v)[16]) {
   return g;
 }
 
+// max |x| over eight bf16 values (as bit patterns: |bf16| ordering == ordering of the low 15 bits)
+__device__ __forceinline__ uint32_t absmax_bits_chunk(const uint4 d, uint32_t m) {
+  const uint32_t w4[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    m = max(m, w4[j] & 0x7fffu);
+    m = max(m, (w4[j] >> 16) & 0x7fffu);
+  }
+  return m;
+}
+
+
+// LDS copy of a row (and of the norm weight): ONE PAD DWORD per 16-element group.  Unpadded, lane t of a wave gathers
+// element idx[16 t + j]; with reorder_index = identity (what the reference's own latency benchmark uses) that is byte
+// 32 t + 2 j -- the same bank for every 8th lane, an 8-way conflict on each of the 16 reads (measured: identity was SLOWER
+// than a random permutation, 47.2 vs 35.8 us at 8192^2).  With 36-byte groups the 64 lanes hit 64 different banks; a random
+// permutation is unaffected.  The pad is applied to a PAIR of int16 indices at once: e + 2 (e >> 4) <= 36861 fits 16 bits.
+__device__ __forceinline__ uint32_t lds_pad_pair(uint32_t w) { return w + (((w >> 4) & 0x0fff0fffu) << 1); }
+__device__ __forceinline__ void lds_store_chunk(uint16_t* row, int c, uint4 d) {       // chunk = 8 elements = half a group
+  uint32_t* p = reinterpret_cast<uint32_t*>(row) + 4 * c + (c >> 1);
+  p[0] = d.x; p[1] = d.y; p[2] = d.z; p[3] = d.w;
+}
+__host__ __device__ constexpr size_t lds_row_bytes(size_t KQ) { return KQ * 2 + KQ / 4; }
+
+
+// x / scale for the per-tensor dynamic scale, without ten instructions of IEEE division per element: q = x * r corrected by
+// two FMAs (Markstein) and the sign of x restored (-0 / s = -0).  With r = RN(1 / scale) this IS the correctly rounded
+// quotient; checked EXHAUSTIVELY on MI355X for every finite bf16 x with |x| <= 4096 scale and every bf16 scale in
+// 2^-100 .. 2^100 (tools/probe_div.hip: 0 mismatches after the bf16 rounding; |x / scale| <= 2688 holds by construction).
+// Scales outside that range take the IEEE division.  `scale` is the bf16-ROUNDED scale torch divides by.
+struct DynDiv {
+  float scale, rcp;
+  bool fast;
+  __device__ __forceinline__ DynDiv(float s, bool enabled) : scale(s), rcp(1.0f / s), fast(enabled && s >= 0x1p-100f && s <= 0x1p100f) {}
+  __device__ __forceinline__ float operator()(float x) const {
+    if (__builtin_expect(fast, 1)) {
+      float q = x * rcp;
+      const float e = __builtin_fmaf(-q, scale, x);
+      q = __builtin_fmaf(e, rcp, q);
+      return __builtin_copysignf(q, x);
+    }
+    return x / scale;
+  }
+};
+
 }  // namespace arcq

@@ -35,15 +35,17 @@ class ModelConfig:
     vocab_size: int = 32000          # LlamaConfig default used by benchmarks/modeling_arc.py:431
     select_num: int = 64
     eps: float = 1e-6
+    attention_bias: bool = False     # benchmarks/benchmark_e2e_arc.py:21-22, 27-77: q/k/v/o (modeling_arc.py:19-56)
+    mlp_bias: bool = False           # gate/up/down
 
 
 # benchmarks/benchmark_e2e_arc.py:26-77
 MODEL_CFGS = {
-    "qwen2.5-7b": ModelConfig("qwen2.5-7b", 28, 28, 3584, 18944),
+    "qwen2.5-7b": ModelConfig("qwen2.5-7b", 28, 28, 3584, 18944, attention_bias=True, mlp_bias=True),
     "llama-2-7b": ModelConfig("llama-2-7b", 32, 32, 4096, 11008),
     "llama-3.1-8b": ModelConfig("llama-3.1-8b", 32, 32, 4096, 14336),
-    "qwen2.5-14b": ModelConfig("qwen2.5-14b", 48, 40, 5120, 13824),
-    "qwen2.5-32b": ModelConfig("qwen2.5-32b", 64, 40, 5120, 27648),
+    "qwen2.5-14b": ModelConfig("qwen2.5-14b", 48, 40, 5120, 13824, attention_bias=True, mlp_bias=True),
+    "qwen2.5-32b": ModelConfig("qwen2.5-32b", 64, 40, 5120, 27648, attention_bias=True, mlp_bias=True),
 }
 
 
@@ -52,8 +54,10 @@ class QLinear:
     ``out_f`` may be the concatenation of several projections that share their input (q|k|v, gate|up): they are
     then quantised as ONE tensor (one per-tensor scale) and computed by one GEMM launch."""
 
-    def __init__(self, in_f, out_f, select_num, device, gen):
+    def __init__(self, in_f, out_f, select_num, device, gen, bias=False):
         w = (torch.randn(out_f, in_f, generator=gen, device=device, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+        # modeling_arc.py:37-40: QLinearLayer(bias=config.attention_bias | mlp_bias); added after the GEMM (`y = y + self.bias`)
+        self.bias = (torch.randn(out_f, generator=gen, device=device, dtype=torch.float32) * 0.02).to(torch.bfloat16) if bias else None
         self.idx = torch.arange(in_f, dtype=torch.int16, device=device)
         scale = torch.max(w).float() / (448.0 * 6.0)
         self.W, self.SFW = agemm.reorder_quantize_w((w / scale).contiguous(), self.idx, select_num)
@@ -67,7 +71,8 @@ class QLinear:
         self.RW, self.RSF = agemm.repack_w(self.W, self.SFW)
 
     def matmul(self, A, SFA, scale, **kw):
-        """GEMM against this weight: the repacked kernel for decode-sized token counts where available."""
+        """GEMM against this weight (+ its bias, in the epilogue): the repacked kernel for decode-sized token counts where available."""
+        kw.setdefault("bias", self.bias)
         if self.RW is not None and agemm.repacked_supported(A.shape[0], self.out_f, self.in_f + self.KE):
             return agemm.matmul_repacked(A, self.RW, SFA, self.RSF, scale, self.out_f, **kw)
         return agemm.matmul(A, self.W, SFA, self.SFW, scale, **kw)
@@ -87,16 +92,24 @@ class DecoderModel:
         sequence attends (causally) over its CURRENT tokens only; attention="cache": attend over the whole KV cache."""
         self.cfg, self.device, self.batch, self.max_len, self.fused = cfg, device, batch, max_len, fused
         self.attention = attention
+        # the down projection's quantiser as its GEMM's prologue: every CU then quantises the whole M x intermediate activation
+        # itself, which only pays while that is small (measured: Qwen2.5-7B, 4 x 18944: slower than the separate launch)
+        self.fused_down = batch * cfg.intermediate_size <= 4 * 8192
+        # which decode linears run their activation quantiser as the GEMM's prologue (one launch instead of two); A-B'ed on
+        # MI355X with tools/e2e_fuse_ab.py, the default is the fastest combination measured there
+        import os
+        self.fuse = set(filter(None, os.environ.get("ARCQ_E2E_FUSE", "qkv,o,gateup").split(",")))
         g = torch.Generator(device=device).manual_seed(0)
         h, it, ke = cfg.hidden_size, cfg.intermediate_size, cfg.select_num
+        ab, mb = cfg.attention_bias, cfg.mlp_bias
         self.layers = []
         for _ in range(cfg.num_layers):
             self.layers.append(dict(
                 ln1=torch.ones(h, dtype=torch.bfloat16, device=device), ln2=torch.ones(h, dtype=torch.bfloat16, device=device),
-                **(dict(qkv=QLinear(h, 3 * h, ke, device, g), gateup=QLinear(h, 2 * it, ke, device, g)) if fused else
-                   dict(q=QLinear(h, h, ke, device, g), k=QLinear(h, h, ke, device, g), v=QLinear(h, h, ke, device, g),
-                        gate=QLinear(h, it, ke, device, g), up=QLinear(h, it, ke, device, g))),
-                o=QLinear(h, h, ke, device, g), down=QLinear(it, h, ke, device, g),
+                **(dict(qkv=QLinear(h, 3 * h, ke, device, g, ab), gateup=QLinear(h, 2 * it, ke, device, g, mb)) if fused else
+                   dict(q=QLinear(h, h, ke, device, g, ab), k=QLinear(h, h, ke, device, g, ab), v=QLinear(h, h, ke, device, g, ab),
+                        gate=QLinear(h, it, ke, device, g, mb), up=QLinear(h, it, ke, device, g, mb))),
+                o=QLinear(h, h, ke, device, g, ab), down=QLinear(it, h, ke, device, g, mb),
                 kv=torch.zeros(2, batch, cfg.num_heads, max_len, h // cfg.num_heads, dtype=torch.bfloat16, device=device)))
             self.layers[-1]["kc"], self.layers[-1]["vc"] = self.layers[-1]["kv"][0], self.layers[-1]["kv"][1]
         if fused:
@@ -127,16 +140,22 @@ class DecoderModel:
         bsz, q_len = tokens.shape
         nh, hd = cfg.num_heads, cfg.hidden_size // cfg.num_heads
         hcur = self.embed[tokens].reshape(bsz * q_len, cfg.hidden_size)
-        h, it = cfg.hidden_size, cfg.intermediate_size
+        h, it, ke = cfg.hidden_size, cfg.intermediate_size, cfg.select_num
+        T = bsz * q_len
         for L in self.layers:
-            A, SFA = agemm.rmsnorm_quantize_x(hcur, L["ln1"], cfg.eps, self.idx_h, cfg.select_num)
+            # ---- attention block: RMSNorm + quantise, q|k|v projection
             if self.fused:
-                qkv = L["qkv"].matmul(A, SFA, L["qkv"].scale)
+                Q = L["qkv"]
+                if "qkv" in self.fuse and Q.RW is not None and agemm.fused_supported(agemm.SRC_RMSNORM, T, Q.out_f, h, ke):
+                    # decode: ONE launch (the quantiser is the GEMM's prologue; bias in its epilogue)
+                    qkv = agemm.rmsnorm_matmul_repacked(hcur, L["ln1"], cfg.eps, self.idx_h, ke, Q.RW, Q.RSF, Q.scale, Q.out_f, bias=Q.bias)
+                else:
+                    A, SFA = agemm.rmsnorm_quantize_x(hcur, L["ln1"], cfg.eps, self.idx_h, ke)
+                    qkv = Q.matmul(A, SFA, Q.scale)
                 q, k, v = qkv[:, :h], qkv[:, h:2 * h], qkv[:, 2 * h:]
             else:
-                q = agemm.matmul(A, L["q"].W, SFA, L["q"].SFW, L["q"].scale)
-                k = agemm.matmul(A, L["k"].W, SFA, L["k"].SFW, L["k"].scale)
-                v = agemm.matmul(A, L["v"].W, SFA, L["v"].SFW, L["v"].scale)
+                A, SFA = agemm.rmsnorm_quantize_x(hcur, L["ln1"], cfg.eps, self.idx_h, ke)
+                q, k, v = (self._ref_linear(L[n], A, SFA, L[n].scale) for n in ("q", "k", "v"))
             q = q.reshape(bsz, q_len, nh, hd).transpose(1, 2)
             if self.fused:      # k|v are adjacent columns of the fused projection: ONE strided copy appends both to the cache
                 L["kv"][:, :, :, pos:pos + q_len] = qkv[:, h:].reshape(bsz, q_len, 2, nh, hd).permute(2, 0, 3, 1, 4)
@@ -149,37 +168,60 @@ class DecoderModel:
             else:
                 att = F.scaled_dot_product_attention(q, k.reshape(bsz, q_len, nh, hd).transpose(1, 2),
                                                      v.reshape(bsz, q_len, nh, hd).transpose(1, 2), is_causal=q_len > 1)
-            att = att.transpose(1, 2).reshape(bsz * q_len, cfg.hidden_size)
+            att = att.transpose(1, 2).reshape(T, cfg.hidden_size)
+            # ---- output projection (+ residual)
             if self.fused:
-                qa, sfa, sa = agemm.reorder_quantize_x_dynamic(att, self.idx_h, cfg.select_num)
-                hcur = L["o"].matmul(qa, sfa, sa, scale_host=L["o"].scale_f, residual=hcur)
+                O_ = L["o"]
+                if "o" in self.fuse and O_.RW is not None and agemm.fused_supported(agemm.SRC_DYNAMIC, T, O_.out_f, h, ke):
+                    hcur, _ = agemm.dynamic_matmul_repacked(att, self.idx_h, ke, O_.RW, O_.RSF, O_.scale_f, O_.out_f, bias=O_.bias, residual=hcur)
+                else:
+                    qa, sfa, sa = agemm.reorder_quantize_x_dynamic(att, self.idx_h, ke)
+                    hcur = O_.matmul(qa, sfa, sa, scale_host=O_.scale_f, residual=hcur)
             else:
-                qa, sfa, sa = self._quant_x(att, self.idx_h, cfg.select_num)
-                hcur = hcur + agemm.matmul(qa, L["o"].W, sfa, L["o"].SFW, sa * L["o"].scale)
-            A, SFA = agemm.rmsnorm_quantize_x(hcur, L["ln2"], cfg.eps, self.idx_h, cfg.select_num)
+                qa, sfa, sa = self._quant_x(att, self.idx_h, ke)
+                hcur = hcur + self._ref_linear(L["o"], qa, sfa, sa * L["o"].scale)
+            # ---- MLP
             if self.fused:
-                # one weight with gate and up rows interleaved (g0, u0, g1, u1, ...)
-                if bsz * q_len > 16:    # prefill: act_fn(gate) * up and its abs-max in the GEMM epilogue, one quantiser launch
-                    act, slots = agemm.matmul_silu_mul(A, L["gateup"].W, SFA, L["gateup"].SFW, L["gateup"].scale)
-                    qa, sfa, sa = agemm.reorder_quantize_x_dynamic(act, self.idx_i, cfg.select_num, absmax_slots=slots)
-                else:                   # decode: the exp-heavy epilogue would sit on the streaming kernel's critical path
-                    G = L["gateup"]                                                                   # measured 29.0 vs 22.8 us
-                    if G.RW is not None and agemm.repacked_supported(A.shape[0], G.out_f, G.in_f + G.KE):
-                        # the repacked GEMM leaves max |silu(g) * u| per row block: the quantiser needs no abs-max launch
-                        gu, slots = agemm.matmul_repacked_silu_absmax(A, G.RW, SFA, G.RSF, G.scale, G.out_f)
-                        qa, sfa, sa = agemm.silu_mul_quantize_x_dynamic(gu, self.idx_i, cfg.select_num, layout=agemm.GU_PAIRS, absmax_slots=slots)
+                Gt, D_ = L["gateup"], L["down"]         # one weight with gate and up rows interleaved (g0, u0, g1, u1, ...)
+                slots = None
+                if "gateup" in self.fuse and Gt.RW is not None and agemm.fused_supported(agemm.SRC_RMSNORM, T, Gt.out_f, h, ke):
+                    # decode: RMSNorm + quantise + gate|up GEMM + bias + SiLU*up + abs-max words in ONE launch
+                    act, slots = agemm.rmsnorm_matmul_repacked_silu(hcur, L["ln2"], cfg.eps, self.idx_h, ke, Gt.RW, Gt.RSF, Gt.scale, Gt.out_f, bias=Gt.bias)
+                else:
+                    A, SFA = agemm.rmsnorm_quantize_x(hcur, L["ln2"], cfg.eps, self.idx_h, ke)
+                    if T > 16:      # prefill: act_fn(gate) * up and its abs-max in the tile GEMM's epilogue
+                        act, slots = agemm.matmul_silu_mul(A, Gt.W, SFA, Gt.SFW, Gt.scale, bias=Gt.bias)
+                    elif Gt.RW is not None and Gt.bias is None and agemm.repacked_supported(T, Gt.out_f, h + ke):
+                        # r1 path: the repacked GEMM leaves max |silu(g) * u| per row block, the quantiser applies SiLU*up itself
+                        gu, slots = agemm.matmul_repacked_silu_absmax(A, Gt.RW, SFA, Gt.RSF, Gt.scale, Gt.out_f)
+                        act = None
                     else:
-                        gu = G.matmul(A, SFA, G.scale)
-                        qa, sfa, sa = agemm.silu_mul_quantize_x_dynamic(gu, self.idx_i, cfg.select_num, layout=agemm.GU_PAIRS)
-                hcur = L["down"].matmul(qa, sfa, sa, scale_host=L["down"].scale_f, residual=hcur)
+                        gu = Gt.matmul(A, SFA, Gt.scale)
+                        act = (F.silu(gu[:, 0::2]) * gu[:, 1::2]).contiguous()
+                if act is None:
+                    qa, sfa, sa = agemm.silu_mul_quantize_x_dynamic(gu, self.idx_i, ke, layout=agemm.GU_PAIRS, absmax_slots=slots)
+                    hcur = D_.matmul(qa, sfa, sa, scale_host=D_.scale_f, residual=hcur)
+                elif ("down" in self.fuse or self.fused_down) and D_.RW is not None and agemm.fused_supported(agemm.SRC_DYNAMIC, T, D_.out_f, it, ke):
+                    hcur, _ = agemm.dynamic_matmul_repacked(act, self.idx_i, ke, D_.RW, D_.RSF, D_.scale_f, D_.out_f, absmax_slots=slots,
+                                                            bias=D_.bias, residual=hcur)
+                else:
+                    qa, sfa, sa = agemm.reorder_quantize_x_dynamic(act, self.idx_i, ke, absmax_slots=slots)
+                    hcur = D_.matmul(qa, sfa, sa, scale_host=D_.scale_f, residual=hcur)
             else:
-                gate = agemm.matmul(A, L["gate"].W, SFA, L["gate"].SFW, L["gate"].scale)
-                up = agemm.matmul(A, L["up"].W, SFA, L["up"].SFW, L["up"].scale)
+                A, SFA = agemm.rmsnorm_quantize_x(hcur, L["ln2"], cfg.eps, self.idx_h, ke)
+                gate = self._ref_linear(L["gate"], A, SFA, L["gate"].scale)
+                up = self._ref_linear(L["up"], A, SFA, L["up"].scale)
                 act = F.silu(gate) * up
-                qa, sfa, sa = self._quant_x(act, self.idx_i, cfg.select_num)
-                hcur = hcur + agemm.matmul(qa, L["down"].W, sfa, L["down"].SFW, sa * L["down"].scale)
+                qa, sfa, sa = self._quant_x(act, self.idx_i, ke)
+                hcur = hcur + self._ref_linear(L["down"], qa, sfa, sa * L["down"].scale)
         hn = F.rms_norm(hcur.view(bsz, q_len, -1)[:, -1], (cfg.hidden_size,), self.norm, cfg.eps)
         return hn @ self.lm_head.t()
+
+    @staticmethod
+    def _ref_linear(lin, A, SFA, scale):
+        """The reference's QLinearLayer.forward (benchmarks/modeling_arc.py:47-56): GEMM, then `y = y + self.bias` as its own op."""
+        y = agemm.matmul(A, lin.W, SFA, lin.SFW, scale)
+        return y if lin.bias is None else y + lin.bias
 
 
 def bench_decode(name="qwen2.5-7b", batch=4, prefill=1024, steps=16, device="cuda:0", repeats=3, layers=None, fused=False,

@@ -88,10 +88,13 @@ class QLinearLayer(nn.Module):
     @torch.no_grad()
     def forward(self, x):
         qx, scale_x, scale, bsz, q_len = x
+        # `y = matmul(...); y = y + bias` (model/qLinearLayer.py:74-76): the bias add runs in the GEMM epilogue with the same
+        # two roundings (the bf16 product, then the bf16 sum), so the result is bit-identical to the two torch steps
+        bias = self.bias if self.bias is None or self.bias.dtype == torch.bfloat16 else None
         if getattr(self, "RW", None) is not None and agemm.repacked_supported(qx.shape[0], self.out_features, qx.shape[1] * 2):
-            y = agemm.matmul_repacked(qx, self.RW, scale_x, self.RSF, scale * self.scale, self.out_features)
+            y = agemm.matmul_repacked(qx, self.RW, scale_x, self.RSF, scale * self.scale, self.out_features, bias=bias)
         else:
-            y = agemm.matmul(qx, self.W, scale_x, self.scale_w, scale * self.scale)
-        if self.bias is not None:
+            y = agemm.matmul(qx, self.W, scale_x, self.scale_w, scale * self.scale, bias=bias)
+        if self.bias is not None and bias is None:
             y = y + self.bias
         return y.reshape(bsz, q_len, -1)

@@ -105,9 +105,9 @@ int64_t arcq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
  *   A [M,K/2], B [N,K/2] packed e2m1; SFA/SFB swizzled ue4m3; K % 64 == 0.
  *   alpha = alpha_host * (alpha_dev ? *alpha_dev : 1): the reference takes a host float
  *   (bindings.cpp:104); alpha_dev lets callers keep the per-tensor scale on the device (no sync).
- *   bias (optional, bf16 [N]) is added after scaling, before rounding.  residual (optional, bf16 [M,N], may alias D)
- *   is added AFTER the bf16 rounding and the sum is rounded again -- the two-step rounding of the caller's
- *   `x + linear(...)` in bf16.  out_dtype: ARCQ_OUT_* (fp32 output adds both in fp32, one result).
+ *   bias (optional, bf16 [N]) and residual (optional, bf16 [M,N], may alias D) are each added to the ROUNDED bf16 result,
+ *   rounding again -- exactly the reference's separate torch ops `y = matmul(...); y = y + bias` (qLinearLayer.py:74-76)
+ *   and the caller's `x + linear(...)`.  out_dtype: ARCQ_OUT_* (fp32 output adds both in fp32, one result).
  *   workspace / workspace_bytes: scratch of at least arcq_gemm_workspace_bytes(M,N,K) (may be NULL if 0). */
 int arcq_gemm_nvfp4(const uint8_t *A, const uint8_t *B, const uint8_t *SFA, const uint8_t *SFB, void *D, int64_t M,
                     int64_t N, int64_t K, float alpha_host, const float *alpha_dev, const void *bias, const void *residual,
@@ -150,7 +150,7 @@ int arcq_silu_mul_quantize_x_dyn(const void *GU, const int16_t *reorder_index, u
 int64_t arcq_gemm_silu_mul_slots(int64_t M, int64_t N, int64_t K);
 int arcq_gemm_nvfp4_silu_mul(const uint8_t *A, const uint8_t *B, const uint8_t *SFA, const uint8_t *SFB, void *ACT,
                              uint32_t *absmax_slots, int64_t M, int64_t N, int64_t K, float alpha_host,
-                             const float *alpha_dev, void *stream);
+                             const float *alpha_dev, const void *bias, void *stream);   /* bias: optional bf16 [N], rows interleaved as B's */
 /* arcq_quantize_x_dyn with max|X| taken from `nslots` precomputed words instead of an abs-max pass. */
 int arcq_quantize_x_dyn_slots(const void *X, const int16_t *reorder_index, uint8_t *QX, uint8_t *SFX, float *scale_out,
                               const uint32_t *absmax_slots, int64_t nslots, int64_t M, int64_t KQ, int64_t KE,
@@ -172,6 +172,14 @@ int arcq_gemm_nvfp4_repacked(const uint8_t *A, const uint8_t *RW, const uint8_t 
                              int64_t M, int64_t N, int64_t K, float alpha_host, const float *alpha_dev,
                              const void *bias, const void *residual, int out_dtype, void *stream);
 
+/* The same contraction through the kernel of the fused decode linears below (arcq_linear_*): identical arguments and
+ * result up to fp32 accumulation order.  arcq_gemm_nvfp4_repacked picks the faster kernel for plain packed activations; this
+ * entry point exists so that a fused linear can be checked BIT FOR BIT against its two-call equivalent
+ * (quantiser + this GEMM): same kernel body, same summation order. */
+int arcq_gemm_nvfp4_repacked_stream(const uint8_t *A, const uint8_t *RW, const uint8_t *SFA, const uint8_t *RSF, void *D,
+                                    int64_t M, int64_t N, int64_t K, float alpha_host, const float *alpha_dev,
+                                    const void *bias, const void *residual, int out_dtype, void *stream);
+
 /* The gate|up projection of a decode step on the repacked path, for weights whose ROWS INTERLEAVE gate and up (g0, u0, g1,
  * u1, ...): D = bf16 [M, N] as arcq_gemm_nvfp4_repacked writes it, and absmax_slots[i], i < ceil(N / 16), = max |silu(g) * u|
  * (bf16 bits, computed from the stored values with the quantiser's own rounding) over the outputs of row block i.
@@ -183,6 +191,39 @@ int arcq_gemm_nvfp4_repacked_silu_absmax(const uint8_t *A, const uint8_t *RW, co
 int arcq_silu_mul_quantize_x_dyn_slots(const void *GU, const int16_t *reorder_index, uint8_t *QX, uint8_t *SFX,
                                        float *scale_out, const uint32_t *absmax_slots, int64_t nslots, int64_t M,
                                        int64_t KQ, int64_t KE, int variant, int layout, void *stream);
+
+/* ---- fused decode linear: the activation quantiser runs as the prologue of the repacked GEMM ------------------------------
+ * One launch replaces  [rmsnorm_quantize_x | abs-max + x/scale + reorder_quantize_x]  ->  matmul (+ bias) (+ residual)
+ * of a decode step (model/qLlamaLayer.py:73-77 + qLinearLayer.py:62-78; benchmarks/modeling_arc.py:211-228,279-310).  Every
+ * workgroup quantises the M <= 16 token rows itself with the quantisers' own group arithmetic, so the result is BIT-IDENTICAL
+ * to arcq_rmsnorm_quantize_x / arcq_quantize_x_dyn followed by arcq_gemm_nvfp4_repacked on the same repacked weight.
+ * arcq_linear_fused_supported(kind, M, N, KQ, KE) tells whether a shape fits (M <= 16, LDS); callers fall back to the two
+ * calls otherwise. */
+#define ARCQ_SRC_RMSNORM 1
+#define ARCQ_SRC_DYNAMIC 2
+int arcq_linear_fused_supported(int kind, int64_t M, int64_t N, int64_t KQ, int64_t KE);
+
+/* D = alpha * matmul(rmsnorm_quantize_x(X, Wn, eps, reorder_index, KE), W) (+ bias) (+ residual); arguments as in
+ * arcq_rmsnorm_quantize_x and arcq_gemm_nvfp4_repacked (K = KQ + KE), alpha = alpha_host * (alpha_dev ? *alpha_dev : 1). */
+int arcq_linear_rmsnorm_repacked(const void *X, const void *Wn, float eps, const int16_t *reorder_index, const uint8_t *RW,
+                                 const uint8_t *RSF, void *D, int64_t M, int64_t N, int64_t KQ, int64_t KE, int variant,
+                                 float alpha_host, const float *alpha_dev, const void *bias, const void *residual, int out_dtype,
+                                 void *stream);
+/* The gate|up projection of the MLP: as above for a weight whose ROWS INTERLEAVE gate and up (g0, u0, g1, u1, ...); ACT = bf16
+ * [M, N/2] receives silu(bf16(alpha*gate)) * bf16(alpha*up) with torch's roundings (what `act_fn(gate) * up`,
+ * model/qLlamaLayer.py:417, has after two GEMMs) and absmax_slots[i], i < ceil(N/16), max |ACT| over row block i (bf16 bits):
+ * arcq_linear_dynamic_repacked then quantises ACT without an abs-max pass.  N % 4 == 0. */
+int arcq_linear_rmsnorm_silu_repacked(const void *X, const void *Wn, float eps, const int16_t *reorder_index, const uint8_t *RW,
+                                      const uint8_t *RSF, void *ACT, uint32_t *absmax_slots, int64_t M, int64_t N, int64_t KQ,
+                                      int64_t KE, int variant, float alpha_host, const float *alpha_dev, const void *bias,
+                                      void *stream);   /* bias: optional bf16 [N], interleaved (g0, u0, g1, u1, ...) like the rows */
+/* scale = max|X| / 2688 (from absmax_slots[0..nslots) when given, else computed from X; written to scale_out[0] if not NULL);
+ * D = alpha_host * scale * matmul(quantize_x(bf16(X / scale), reorder_index, KE), W) (+ bias) (+ residual): the reference's
+ * NVFP4_reorder_quantize_x + QLinearLayer.forward with alpha_host = the weight's per-tensor scale. */
+int arcq_linear_dynamic_repacked(const void *X, const int16_t *reorder_index, const uint8_t *RW, const uint8_t *RSF, void *D,
+                                 float *scale_out, const uint32_t *absmax_slots, int64_t nslots, int64_t M, int64_t N, int64_t KQ,
+                                 int64_t KE, int variant, float alpha_host, const void *bias, const void *residual, int out_dtype,
+                                 void *stream);
 
 #ifdef __cplusplus
 }

@@ -509,7 +509,7 @@ def test_repacked_weight_gemm_equals_the_reference_layout_gemm():
         bias = torch.randn(N, generator=g).to(torch.bfloat16).to(DEV)
         res = torch.randn(M, N, generator=g).to(torch.bfloat16).to(DEV)
         dev_scale = torch.tensor(alpha / 0.5, dtype=torch.float32, device=DEV)
-        want16 = res + (got32 + bias.float()).to(torch.bfloat16)
+        want16 = res + (got32.to(torch.bfloat16) + bias)          # the reference's op order: matmul -> + bias -> x + y, each in bf16
         got16 = ag.matmul_repacked(A, RW, SFA, RSF, dev_scale, N, scale_host=0.5, bias=bias, residual=res)
         assert torch.equal(got16, want16), (M, N, K)
     assert not ag.repacked_supported(17, 256, 256) and not ag.repacked_supported(5, 256, 19008)
@@ -602,7 +602,7 @@ def test_gemm_epilogue_operands_on_every_kernel():
         res = torch.randn(M, N, generator=g).to(torch.bfloat16).to(DEV)
         plain32 = ag.matmul(A, B, SFA, SFB, alpha, out_dtype=torch.float32)
         assert torch.equal(ag.matmul(A, B, SFA, SFB, 2 * alpha, out_dtype=torch.float32), 2 * plain32)
-        want = res + (plain32 + bias.float()).to(torch.bfloat16)          # bf16(alpha*acc + bias), then the bf16 add
+        want = res + (plain32.to(torch.bfloat16) + bias)                  # matmul -> + bias -> + residual, each rounded to bf16 (the reference's ops)
         dev_scale = torch.tensor(alpha / 0.5, dtype=torch.float32, device=DEV)
         got = ag.matmul(A, B, SFA, SFB, dev_scale, scale_host=0.5, bias=bias, residual=res)
         assert torch.equal(got, want), (M, N, KQ)
@@ -653,3 +653,129 @@ def test_gemm_fuzz_random_shapes_against_fp64_matmul():
         assert bool((err <= 2e-6 * wabs + 1e-30).all()), (case, M, N, K, float((err / (wabs + 1e-30)).max()))
         got16 = ag.matmul(A, B, SFA, SFB, alpha).double()
         assert bool(((got16 - want).abs() <= want.abs() * 2.0 ** -8 + 2e-6 * wabs + 1e-30).all()), (case, M, N, K)
+
+
+# ------------------------------------------------------------------------------------------------ fused decode linears
+def _oracle_dyn_quant(x_dev, idx_dev, KE, variant):
+    """The reference's NVFP4_reorder_quantize_x on the CPU: torch's scale and division, the ORACLE's quantiser."""
+    x = x_dev.cpu()
+    # torch's GPU true-divide by a Python scalar multiplies by the fp32 reciprocal (BinaryDivTrueKernel): the scale of
+    # `torch.max(x.abs()).float() / (448.0*6.0)` (model/qLlamaLayer.py:74) is amax * fl(1/2688) there; the CPU would divide
+    scale = torch.max(x.abs()).float() * torch.tensor(1.0 / (448.0 * 6.0), dtype=torch.float32)
+    # torch on the GPU divides a bf16 tensor by a 0-dim fp32 tensor in bf16: the scale is rounded to bf16, the quotient formed
+    # in fp32 and rounded once (BinaryFunctor<BFloat16, BFloat16, BFloat16, DivFunctor>); stated explicitly here for the CPU
+    xs = (x.float() / scale.to(torch.bfloat16).float()).to(torch.bfloat16)
+    q, sf = O.quantize_x(bits(xs.contiguous()), idx_dev.cpu().numpy(), KE, variant, sf_fill=0)
+    return q, sf, float(scale)
+
+
+FUSED_CASES = [
+    # M, N, KQ, KE : Qwen2.5-7B decode shapes (G32) and small / G16 / ragged ones
+    (4, 10752, 3584, 64),      # q|k|v
+    (4, 3584, 3584, 64),       # o_proj
+    (1, 4096, 4096, 64),       # config[1]
+    (16, 272, 2048, 64),
+    (3, 1000, 2048, 128),
+    (2, 48, 2048, 2048),       # every channel carries a residual
+    (5, 520, 4096, 0),
+]
+
+
+@pytest.mark.parametrize("M,N,KQ,KE", FUSED_CASES)
+def test_fused_rmsnorm_and_dynamic_linears_equal_the_separate_launches_and_the_oracle(M, N, KQ, KE):
+    """rmsnorm_matmul_repacked == rmsnorm_quantize_x + matmul_repacked, dynamic_matmul_repacked == reorder_quantize_x_dynamic +
+    matmul_repacked, BIT FOR BIT (bias, residual, bf16 and fp32 output), and both within the GEMM tolerance of the CPU oracle
+    chain (O.rmsnorm_quantize_x / O.quantize_x on torch's x/scale, then O.gemm): the fused prologue is the quantiser."""
+    ag = _agemm()
+    variant = ag.variant_for_kq(KQ)
+    g = torch.Generator().manual_seed(M * 1000 + N + KQ)
+    x = outlier_activations(M, KQ, 900 + M + N).to(DEV)
+    wn = (torch.rand(KQ, generator=g) + 0.5).to(torch.bfloat16).to(DEV)
+    w, sw = prescale((torch.rand(N, KQ, generator=g) * 2 - 1.0).to(torch.bfloat16))
+    sw = float(sw)
+    idx = random_perm(KQ, 7 + KQ).to(DEV)
+    QW, SFW = ag.reorder_quantize_w(w.to(DEV), idx, KE)
+    RW, RSF = ag.repack_w(QW, SFW)
+    bias = torch.randn(N, generator=g).to(torch.bfloat16).to(DEV)
+    res = torch.randn(M, N, generator=g).to(torch.bfloat16).to(DEV)
+    ow, owsf = QW.cpu().numpy(), SFW.cpu().numpy()
+
+    if 2048 <= KQ <= 8192:
+        assert ag.fused_supported(ag.SRC_RMSNORM, M, N, KQ, KE)
+        A, SFA = ag.rmsnorm_quantize_x(x, wn, 1e-6, idx, KE)
+        for kw in (dict(), dict(bias=bias), dict(residual=res), dict(bias=bias, residual=res, out_dtype=torch.float32)):
+            want = ag.matmul_repacked(A, RW, SFA, RSF, sw, N, kernel="stream", **kw)
+            got = ag.rmsnorm_matmul_repacked(x, wn, 1e-6, idx, KE, RW, RSF, sw, N, **kw)
+            assert torch.equal(got, want), (M, N, KQ, KE, list(kw))
+        dev_scale = torch.tensor(sw / 0.5, dtype=torch.float32, device=DEV)
+        assert torch.equal(ag.rmsnorm_matmul_repacked(x, wn, 1e-6, idx, KE, RW, RSF, dev_scale, N, scale_host=0.5),
+                           ag.matmul_repacked(A, RW, SFA, RSF, sw, N, kernel="stream"))
+        oq, osf = O.rmsnorm_quantize_x(bits(x), bits(wn), 1e-6, idx.cpu().numpy(), KE, variant, sf_fill=0)
+        if N * (KQ + KE) <= 16_000_000:
+            _, want_e, wabs = O.gemm(oq, ow, osf, owsf, sw, want_abs=True)
+            got32 = ag.rmsnorm_matmul_repacked(x, wn, 1e-6, idx, KE, RW, RSF, sw, N, out_dtype=torch.float32).cpu().numpy()
+            assert np.all(np.abs(got32 - want_e) <= 2e-6 * wabs + 1e-30)
+
+    assert ag.fused_supported(ag.SRC_DYNAMIC, M, N, KQ, KE)
+    qa, sfa, sa = ag.reorder_quantize_x_dynamic(x, idx, KE)
+    slots = None
+    for use_slots in (False, True):
+        if use_slots:      # abs-max words as a producing kernel leaves them: one per 16 columns (bf16 magnitude bits), any split works
+            mag = (x.view(torch.int16).to(torch.int32) & 0x7FFF)
+            slots = torch.stack([c.max() for c in mag.reshape(-1).split(997)]).to(torch.int32).contiguous()
+        for kw in (dict(), dict(bias=bias, residual=res), dict(residual=res, out_dtype=torch.float32)):
+            want = ag.matmul_repacked(qa, RW, sfa, RSF, sa, N, scale_host=sw, kernel="stream", **kw)
+            got, got_scale = ag.dynamic_matmul_repacked(x, idx, KE, RW, RSF, sw, N, absmax_slots=slots, **kw)
+            assert float(got_scale) == float(sa)
+            assert torch.equal(got, want), (M, N, KQ, KE, use_slots, list(kw))
+    oq, osf, osc = _oracle_dyn_quant(x, idx, KE, variant)
+    assert osc == float(sa) and np.array_equal(qa.cpu().numpy(), oq)
+    if N * (KQ + KE) <= 16_000_000:
+        _, want_e, wabs = O.gemm(oq, ow, osf, owsf, np.float32(osc) * np.float32(sw), want_abs=True)
+        got32, _ = ag.dynamic_matmul_repacked(x, idx, KE, RW, RSF, sw, N, out_dtype=torch.float32)
+        assert np.all(np.abs(got32.cpu().numpy() - want_e) <= 4e-6 * wabs + 1e-30)
+
+
+@pytest.mark.parametrize("M,IT,KQ", [(4, 18944, 3584), (1, 2048, 2048), (16, 320, 2048), (3, 8192, 4096)])
+def test_fused_mlp_pair_equals_the_separate_launches(M, IT, KQ):
+    """The decode MLP in two launches -- rmsnorm_matmul_repacked_silu (RMSNorm + quantise + gate|up GEMM + SiLU*up + abs-max
+    words) and dynamic_matmul_repacked(absmax_slots=...) (dynamic quantise + down GEMM + residual) -- against the seven-launch
+    chain it replaces, bit for bit; the Qwen2.5-7B case gathers its 18944-wide activation from global memory (the 152 KB image
+    leaves no LDS to stage it)."""
+    import torch.nn.functional as F
+    ag = _agemm()
+    KE, N = 64, 2 * IT
+    g = torch.Generator().manual_seed(IT + M)
+    x = outlier_activations(M, KQ, 31 + M).to(DEV)
+    wn = (torch.rand(KQ, generator=g) + 0.5).to(torch.bfloat16).to(DEV)
+    wgu, sgu = prescale((torch.rand(N, KQ, generator=g) * 2 - 1.0).to(torch.bfloat16))       # rows: g0, u0, g1, u1, ...
+    idx = random_perm(KQ, 3).to(DEV)
+    RWg, RSFg = ag.repack_w(*ag.reorder_quantize_w(wgu.to(DEV), idx, KE))
+    alpha = float(sgu) * 3e-3                                                                # activations of order 1
+    y = ag.rmsnorm_matmul_repacked(x, wn, 1e-6, idx, KE, RWg, RSFg, alpha, N)
+    y_auto = ag.matmul_repacked(*ag.rmsnorm_quantize_x(x, wn, 1e-6, idx, KE)[:1], RWg, ag.rmsnorm_quantize_x(x, wn, 1e-6, idx, KE)[1], RSFg, alpha, N)
+    assert _max_bf16_ulp_diff(bits(y.cpu()), bits(y_auto.cpu())) <= 1            # the default packed-path kernel: same products, another summation order
+    want_act = F.silu(y[:, 0::2]) * y[:, 1::2]
+    act, slots = ag.rmsnorm_matmul_repacked_silu(x, wn, 1e-6, idx, KE, RWg, RSFg, alpha, N)
+    assert act.shape == (M, IT) and torch.equal(act, want_act)
+    assert slots.shape == ((N + 15) // 16,) and int(slots.max()) == (int(want_act.abs().max().view(torch.int16)) & 0x7FFF)
+    # direct check of the SiLU epilogue against a CPU statement of torch's two roundings (the GEMM itself is oracle-checked above)
+    yc = y.cpu().float()
+    silu_cpu = (yc[:, 0::2] / (1.0 + torch.exp(-yc[:, 0::2]))).to(torch.bfloat16)
+    act_cpu = (silu_cpu.float() * yc[:, 1::2]).to(torch.bfloat16)
+    same = (bits(act_cpu) == bits(act.cpu()))
+    assert same.mean() > 0.999 and _max_bf16_ulp_diff(bits(act_cpu), bits(act.cpu())) <= 1       # exp: ocml on the GPU, libm here
+    # down projection
+    Nd = 1024 if IT > 4096 else 256
+    idx_i = random_perm(IT, 5).to(DEV)
+    wd, sd = prescale((torch.rand(Nd, IT, generator=g) * 2 - 1.0).to(torch.bfloat16))
+    RWd, RSFd = ag.repack_w(*ag.reorder_quantize_w(wd.to(DEV), idx_i, KE))
+    res = torch.randn(M, Nd, generator=g).to(torch.bfloat16).to(DEV)
+    if not ag.fused_supported(ag.SRC_DYNAMIC, M, Nd, IT, KE):
+        return
+    qa, sfa, sa = ag.reorder_quantize_x_dynamic(want_act.contiguous(), idx_i, KE)
+    want = ag.matmul_repacked(qa, RWd, sfa, RSFd, sa, Nd, scale_host=float(sd), residual=res, kernel="stream")
+    got, got_scale = ag.dynamic_matmul_repacked(act, idx_i, KE, RWd, RSFd, float(sd), Nd, absmax_slots=slots, residual=res)
+    assert float(got_scale) == float(sa) and torch.equal(got, want)
+    got2, _ = ag.dynamic_matmul_repacked(act, idx_i, KE, RWd, RSFd, float(sd), Nd, residual=res)       # abs-max recomputed in the kernel
+    assert torch.equal(got2, want)

@@ -1,7 +1,15 @@
-"""Run a few graph-replayed decode steps of the Qwen2.5-7B-shape model (for rocprofv3 --kernel-trace)."""
-import os, sys, json
+#!/usr/bin/env python3
+"""Run a few-layer Qwen2.5-7B-shape decode (fused path) so that `rocprofv3 --kernel-trace --stats -- python tools/e2e_profile.py`
+shows where a decode step's time goes.  usage: e2e_profile.py [layers] [attention]"""
+import json
+import os
+import sys
+
+import torch
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from arcquant_amd.e2e import bench_decode
-layers = int(sys.argv[1]) if len(sys.argv) > 1 else 28
-fused = len(sys.argv) > 2 and sys.argv[2] == "fused"
-print(json.dumps(bench_decode("qwen2.5-7b", batch=4, prefill=1024, steps=8, repeats=1, layers=layers, fused=fused)))
+from arcquant_amd import e2e  # noqa: E402
+
+layers = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+att = sys.argv[2] if len(sys.argv) > 2 else "current"
+print(json.dumps(e2e.bench_decode("qwen2.5-7b", batch=4, prefill=1024, steps=16, layers=layers, fused=True, attention=att)))
