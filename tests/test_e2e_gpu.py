@@ -61,3 +61,81 @@ def test_reference_protocol_benchmark_runs_graph_and_eager():
             assert out["e2e_ms"][0] > out["decode_ms"][0] * 0.5 and out["peak_memory_gb"] > 0
     finally:
         del e2e.MODEL_CFGS["toy"]
+
+
+def test_fused_decoder_layer_matches_the_oracle_stage_by_stage():
+    """One decoder layer of the harness on the fused decode path (three fused launches + the fused down projection), every
+    arcq stage against the CPU ORACLE on the stage's own input, BIT FOR BIT:
+        q|k|v   = O.rmsnorm_quantize_x -> O.gemm (bf16) + bias
+        o_proj  = torch's abs-max / division (GPU semantics) + O.quantize_x -> O.gemm + bias, + residual
+        act     = O.rmsnorm_quantize_x -> O.gemm + bias -> silu(gate) * up with torch's two roundings
+        down    = abs-max / division + O.quantize_x -> O.gemm + bias, + residual
+    and the stages chained by hand reproduce DecoderModel.forward exactly (so forward() IS these ops).  Only the attention
+    between them is torch's (flash on the GPU against fp32 math on the CPU: compared within 1e-2).  A chained end-to-end
+    tolerance would hide a wrong stage -- one bf16 bit of attention noise already moves the logits by several percent through
+    two re-quantisations -- which is why each stage is pinned on its own."""
+    import numpy as np
+    import torch.nn.functional as F
+    from arcquant_amd import agemm as ag
+    from oracle import oracle as O
+    from tests.util import bits, from_bits
+    e2e, _ = _toy()
+    cfg = e2e.ModelConfig("toy1", num_layers=1, num_heads=4, hidden_size=2048, intermediate_size=4096, vocab_size=256,
+                          attention_bias=True, mlp_bias=True)
+    dev = torch.device("cuda:0")
+    bsz, q_len = 2, 3
+    tok = torch.randint(0, cfg.vocab_size, (bsz, q_len), device=dev)
+    with torch.no_grad():
+        model = e2e.DecoderModel(cfg, bsz, 8, dev, fused=True, attention="cache")
+        model.fuse = {"qkv", "o", "gateup", "down"}
+        logits = model.forward(tok, 0)
+    L = model.layers[0]
+    h, it, ke, nh = cfg.hidden_size, cfg.intermediate_size, cfg.select_num, cfg.num_heads
+    hd, T = h // nh, bsz * q_len
+    idx_h, idx_i = model.idx_h.cpu().numpy(), model.idx_i.cpu().numpy()
+
+    def oracle_linear(qx, sfx, alpha, lin, residual=None):
+        db, _ = O.gemm(qx, lin.W.cpu().numpy(), sfx, lin.SFW.cpu().numpy(), np.float32(alpha) * np.float32(lin.scale_f))
+        y = from_bits(db) + lin.bias.cpu()                          # bf16 product, then the bf16 bias add (qLinearLayer.py:74-76)
+        return y if residual is None else residual.cpu() + y
+
+    def oracle_dyn_quant(x, idx):                                  # qLlamaLayer.py:73-77 with torch-on-GPU semantics
+        x = x.cpu()
+        scale = torch.max(x.abs()).float() * torch.tensor(1.0 / 2688.0, dtype=torch.float32)
+        xs = (x.float() / scale.to(torch.bfloat16).float()).to(torch.bfloat16)
+        q, sf = O.quantize_x(bits(xs), idx, ke, O.G16, sf_fill=0)
+        return q, sf, float(scale)
+
+    def same(a, b):
+        return torch.equal(a.cpu(), b.cpu())
+
+    with torch.no_grad():
+        hcur = model.embed[tok].reshape(T, h)
+        Q = L["qkv"]
+        qkv = ag.rmsnorm_matmul_repacked(hcur, L["ln1"], cfg.eps, model.idx_h, ke, Q.RW, Q.RSF, Q.scale, Q.out_f, bias=Q.bias)
+        qx, sfx = O.rmsnorm_quantize_x(bits(hcur.cpu()), bits(L["ln1"].cpu()), cfg.eps, idx_h, ke, O.G16, sf_fill=0)
+        assert same(qkv, oracle_linear(qx, sfx, 1.0, Q))
+        q, k, v = (qkv[:, i * h:(i + 1) * h].reshape(bsz, q_len, nh, hd).transpose(1, 2) for i in range(3))
+        att = F.scaled_dot_product_attention(q, k, v, is_causal=True).transpose(1, 2).reshape(T, h)
+        att_cpu = F.scaled_dot_product_attention(q.float().cpu(), k.float().cpu(), v.float().cpu(), is_causal=True)
+        att_cpu = att_cpu.to(torch.bfloat16).transpose(1, 2).reshape(T, h)
+        assert float((att.cpu().float() - att_cpu.float()).norm() / att_cpu.float().norm()) < 1e-2
+        O_ = L["o"]
+        h2, _ = ag.dynamic_matmul_repacked(att, model.idx_h, ke, O_.RW, O_.RSF, O_.scale_f, O_.out_f, bias=O_.bias, residual=hcur)
+        qa, sfa, sa = oracle_dyn_quant(att, idx_h)
+        assert same(h2, oracle_linear(qa, sfa, sa, O_, residual=hcur))
+        Gt = L["gateup"]
+        act, slots = ag.rmsnorm_matmul_repacked_silu(h2, L["ln2"], cfg.eps, model.idx_h, ke, Gt.RW, Gt.RSF, Gt.scale, Gt.out_f, bias=Gt.bias)
+        qx, sfx = O.rmsnorm_quantize_x(bits(h2.cpu()), bits(L["ln2"].cpu()), cfg.eps, idx_h, ke, O.G16, sf_fill=0)
+        gu = oracle_linear(qx, sfx, 1.0, Gt).float()               # interleaved (g0, u0, g1, u1, ...)
+        g_, u_ = gu[:, 0::2], gu[:, 1::2]
+        act_cpu = ((g_ / (1.0 + torch.exp(-g_))).to(torch.bfloat16).float() * u_).to(torch.bfloat16)
+        assert (bits(act.cpu()) == bits(act_cpu)).mean() > 0.999 and same(act, act_cpu) or \
+            float((act.cpu().float() - act_cpu.float()).abs().max()) <= 2.0 ** -7 * float(act_cpu.float().abs().max())   # exp: ocml vs libm
+        D_ = L["down"]
+        h3, _ = ag.dynamic_matmul_repacked(act, model.idx_i, ke, D_.RW, D_.RSF, D_.scale_f, D_.out_f, absmax_slots=slots, bias=D_.bias, residual=h2)
+        qa, sfa, sa = oracle_dyn_quant(act, idx_i)
+        assert same(h3, oracle_linear(qa, sfa, sa, D_, residual=h2))
+        # the chain above IS what forward() runs
+        hn = F.rms_norm(h3.view(bsz, q_len, -1)[:, -1], (h,), model.norm, cfg.eps)
+        assert torch.equal(hn @ model.lm_head.t(), logits)
