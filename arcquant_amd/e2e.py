@@ -99,6 +99,7 @@ class DecoderModel:
         # MI355X with tools/e2e_fuse_ab.py, the default is the fastest combination measured there
         import os
         self.fuse = set(filter(None, os.environ.get("ARCQ_E2E_FUSE", "qkv,o,gateup").split(",")))
+        self.decode_attention = os.environ.get("ARCQ_E2E_DECODE_ATTENTION", "sdpa")     # "sdpa" | "bmm" (torch glue, outside SURVEY 8)
         g = torch.Generator(device=device).manual_seed(0)
         h, it, ke = cfg.hidden_size, cfg.intermediate_size, cfg.select_num
         ab, mb = cfg.attention_bias, cfg.mlp_bias
@@ -162,7 +163,13 @@ class DecoderModel:
             else:
                 L["kc"][:, :, pos:pos + q_len] = k.reshape(bsz, q_len, nh, hd).transpose(1, 2)
                 L["vc"][:, :, pos:pos + q_len] = v.reshape(bsz, q_len, nh, hd).transpose(1, 2)
-            if self.attention == "cache":
+            if self.attention == "cache" and q_len == 1 and self.decode_attention == "bmm":
+                # one query per sequence: attention is two batched GEMVs over the cache (torch.bmm = rocBLAS) around a softmax;
+                # the flash kernel SDPA picks here is built for long queries (53 us per layer for 60 MB of K/V: 1.1 TB/s)
+                kc, vc = L["kc"][:, :, :pos + 1], L["vc"][:, :, :pos + 1]
+                sc = torch.matmul(q, kc.transpose(2, 3)) * (hd ** -0.5)                      # [bsz, nh, 1, pos+1]
+                att = torch.matmul(torch.softmax(sc.float(), dim=-1).to(q.dtype), vc)
+            elif self.attention == "cache":
                 att = F.scaled_dot_product_attention(q, L["kc"][:, :, :pos + q_len], L["vc"][:, :, :pos + q_len],
                                                      is_causal=(q_len > 1 and pos == 0))
             else:
