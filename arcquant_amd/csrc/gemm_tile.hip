@@ -26,6 +26,25 @@
 
 namespace arcq {
 
+#ifdef ARCQ_STREAM_STAMPS
+// DIAGNOSTIC build only: the in-kernel clock of the K loop = delta s_memtime / delta s_memrealtime x 100 MHz
+// (MI355X_MICROARCH.md, "DVFS give-back" item 6), stamped once around the loop by wave 0 of every workgroup into a buffer
+// nothing else reads (tools/tile_clock.py).  The product library has no stamps.
+static unsigned long long* g_tile_stamps = nullptr;
+extern "C" void arcq_debug_set_tile_stamps(void* p) { g_tile_stamps = reinterpret_cast<unsigned long long*>(p); }
+#define ARCQ_TILE_STAMP(k)                                                                                     \
+  do {                                                                                                         \
+    if (p.stamps && tid == 0) {                                                                                \
+      unsigned long long t0_, t1_;                                                                             \
+      asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_), "=s"(t1_)::"memory"); \
+      p.stamps[(size_t)blockIdx.x * 4 + 2 * (k)] = t0_;                                                        \
+      p.stamps[(size_t)blockIdx.x * 4 + 2 * (k) + 1] = t1_;                                                    \
+    }                                                                                                          \
+  } while (0)
+#else
+#define ARCQ_TILE_STAMP(k) do { } while (0)
+#endif
+
 // kStagger (8-wave tiles): the two waves of a SIMD (w and w + 4) run half a step apart -- waves 0-3 multiply step k and
 // then stage step k+1, waves 4-7 stage step k+2 FIRST (into the buffer step k was just read from, after the barrier)
 // and then multiply step k+1 -- so that one wave's dequantise/ds_write phase overlaps the other's MFMA phase instead
@@ -298,6 +317,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
   // the second-dispatched half of an 8-wave workgroup loses every issue arbitration against its SIMD partner at equal
   // priority; a static priority for it (never flipped) measured +0.8 % (1192-1203 -> 1209-1212 TFLOP/s)
   if (WAVES_M * WAVES_N == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+  ARCQ_TILE_STAMP(0);
   if constexpr (kPipe) {
     for (; kt + 1 < a_end; kt += 2) {
       k_step_pipe(kt, lds_a0, lds_b0, lds_a1, lds_b1);
@@ -311,6 +331,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
     }
     if (kt < a_end) k_step(kt, lds_a0, lds_b0, lds_a1, lds_b1);
   }
+  ARCQ_TILE_STAMP(1);
 
   // ---- epilogue.  16x16 tiles: lane holds D[m = +(lane & 15)][n = +4*(lane >> 4) + r], r = 0..3.
   //      32x32 tiles: lane holds D[m = +(lane & 31)][n = +8*g + 4*(lane >> 5) + r], g = 0..3, r = 0..3.
@@ -424,6 +445,9 @@ static int launch_tile(const GemmArgs& a, hipStream_t stream, bool allow_split =
   p.tiles_n = (a.N + BN - 1) / BN;
   p.splits = 1; p.atoms_per_split = a.K / 64; p.partial = nullptr;
   p.epi = a.epilogue; p.slots = a.absmax_slots;
+#ifdef ARCQ_STREAM_STAMPS
+  p.stamps = g_tile_stamps;
+#endif
   if (allow_split && a.epilogue == kEpiPlain) {
     tile_split(a.M, a.N, a.K, BM, BN, &p.splits, &p.atoms_per_split);
     if (p.splits > 1) {

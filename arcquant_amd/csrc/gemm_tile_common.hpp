@@ -30,6 +30,9 @@ struct TileParams {
   // silu(gate)*up and slots[blockIdx.x] receives this workgroup's max |D| (bit pattern) for the dynamic quantiser
   int epi;
   unsigned int* slots;
+#ifdef ARCQ_STREAM_STAMPS      // DIAGNOSTIC build only (make diag): [workgroup][4] = s_memtime / s_memrealtime before and after the K loop
+  unsigned long long* stamps;
+#endif
 };
 
 constexpr int kBK = 64;                 // K elements per step = one scale-factor atom column (4 groups)

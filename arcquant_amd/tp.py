@@ -9,6 +9,20 @@ atom = 32 packed bytes), so packed bytes and swizzled scale bytes slice cleanly 
 pair is never separated from its scale.  Every rank contracts its K slice with the same alpha into fp32
 partials and the partials are summed with ONE all-reduce.
 
+Column -> row hand-off (the MLP's gate|up -> down, attention's q|k|v -> o): after a column-parallel linear every rank holds
+only ITS columns of the activation, and the following row-parallel linear quantises that activation with ONE per-tensor
+scale (max|x| / 2688, model/qLlamaLayer.py:73-77) and a reorder_index over the WHOLE row.  Two ways, both here:
+
+  A  ``handoff_gather``: all-gather the bf16 column blocks ((p-1)/p * M * N_inter * 2 B per rank), quantise the full row
+     replicated, slice the packed bytes to the rank's K range (``shard_k``).  Bit-identical to the unsharded layer, any
+     reorder_index.  Decode (M = 4, Llama-3-70B, N_inter = 28672): 201 KB per rank and layer -- latency-bound, fine;
+     prefill (M = 4096): 206 MB -- as much as the weights: use B.
+  B  ``handoff_local_scale``: every rank quantises only its own columns with a SHARD-LOCAL reorder_index / select_num
+     (calibrated per shard; the weight shard is quantised with the same local index), and only the per-tensor scale is
+     global: one all-reduce(MAX) of a 4-byte abs-max word.  No activation moves.  Each rank's bytes equal the unsharded
+     quantiser run on that rank's column slice with the global scale; the layer equals the unsharded one whose
+     reorder_index is the concatenation of the local ones.
+
 All slicing helpers are pure tensor ops (device-agnostic), so the CPU tests exercise them with gloo.
 """
 from __future__ import annotations
@@ -143,3 +157,38 @@ class RowParallelARCLinear:
         if self.bias is not None:
             part = part + self.bias.float()
         return part.to(out_dtype)
+
+
+# ---- column -> row hand-off ------------------------------------------------------------------------------------------------
+def absmax_word(x: torch.Tensor) -> torch.Tensor:
+    """max |x| of a bf16 tensor as ONE int32 word of bf16 magnitude bits -- the abs-max slot format of
+    ``agemm.reorder_quantize_x_dynamic(..., absmax_slots=...)``; integer max == float max for magnitudes."""
+    if x.dtype != torch.bfloat16:
+        raise ValueError("absmax_word: bf16 tensor expected")
+    return (x.contiguous().view(torch.int16).to(torch.int32) & 0x7FFF).max().reshape(1)
+
+
+def handoff_gather(y_local: torch.Tensor, widths, group=None) -> torch.Tensor:
+    """Hand-off A: all-gather the column blocks of a column-parallel output; the caller quantises the full row (replicated)
+    and slices its K range with ``shard_k``.  Moves (p-1) * M * max(widths) * 2 bytes per rank."""
+    return all_gather_columns(y_local, widths, group=group)
+
+
+def handoff_local_scale(y_local: torch.Tensor, group=None) -> torch.Tensor:
+    """Hand-off B: the GLOBAL per-tensor abs-max word from the rank-local ones: one all-reduce(MAX) of 4 bytes.  Feed it to
+    ``agemm.reorder_quantize_x_dynamic(y_local, local_reorder_index, KE_local, absmax_slots=word)``: the rank quantises only
+    its own columns, with the scale the unsharded layer would use."""
+    import torch.distributed as dist
+    word = absmax_word(y_local)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(word, op=dist.ReduceOp.MAX, group=group)
+    return word
+
+
+def handoff_bytes_per_rank(M: int, n_inter: int, world: int, mode: str) -> int:
+    """Bytes a rank sends per column -> row hand-off (documentation / bench)."""
+    if mode == "gather":
+        return (world - 1) * M * ((n_inter + world - 1) // world) * 2
+    if mode == "local_scale":
+        return 4 * (world - 1)
+    raise ValueError(mode)

@@ -477,7 +477,7 @@ def main():
     # bench.py cannot run rocprofv3 on itself, so the number is read from profiles/ and labelled as such
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_tile_gemm.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_tile_gemm.json")) as f:
             traffic = json.load(f)["per_launch"]["hbm_traffic_bytes"]
     except Exception:
         pass
@@ -498,7 +498,7 @@ def main():
                                    else f"column-parallel x{world} (no collective)")},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic,
-                     "traffic_source": "profiles/r01_pmc_tile_gemm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)",
+                     "traffic_source": "profiles/r02_pmc_tile_gemm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)",
                      "kernel": "arcq::gemm_tile_kernel", "kernel_us": round(kern_us, 2),
                      "frac_of_fp4_peak": round(achieved / PEAK_FP4_TFLOPS, 4),
                      "note": "NVFP4 (ue4m3 scale per 16) has no exact mapping onto gfx950's E8M0-per-32 scaled fp4 MFMA; the exact "

@@ -113,3 +113,112 @@ def test_shard_n_is_a_valid_operand_for_the_oracle():
         q, sf = tp.shard_n(torch.from_numpy(qw), torch.from_numpy(sfw), n0, n1)
         assert sf.numel() == O.sf_alloc_bytes(n1 - n0, K) or (n1 - n0) % 128 != 0
         assert np.array_equal(O.dequant(q.numpy(), sf.numpy()), full[n0:n1])
+
+
+# ---------------------------------------------------------------------------- column -> row hand-off
+def _torch_gpu_scale_and_prescale(x, amax_bits):
+    """scale = max|x| / 2688 and bf16(x / scale) with torch-on-GPU semantics (see tests/test_gpu_parity._oracle_dyn_quant)."""
+    amax = torch.tensor([amax_bits], dtype=torch.int32).to(torch.int16).view(torch.bfloat16).float()[0]
+    scale = amax * torch.tensor(1.0 / 2688.0, dtype=torch.float32)
+    xs = (x.float() / scale.to(torch.bfloat16).float()).to(torch.bfloat16)
+    return float(scale), xs
+
+
+def _mlp_problem(world):
+    """A column-parallel linear (N_inter = 1024) followed by a row-parallel one (K = 1024 -> 192), M = 5 tokens."""
+    M, H, NI, N2, KE = 5, 256, 1024, 192, 64
+    g = torch.Generator().manual_seed(11)
+    x, sx = prescale(outlier_activations(M, H, 12))
+    w1, s1 = prescale((torch.rand(NI, H, generator=g) * 2 - 1).to(torch.bfloat16))
+    w2 = (torch.rand(N2, NI, generator=g) * 2 - 1).to(torch.bfloat16)
+    idx1 = random_perm(H, 13).numpy()
+    idx2 = random_perm(NI, 14).numpy()                              # hand-off A: a reorder_index over the WHOLE intermediate row
+    shard = NI // world
+    local_idx = [random_perm(shard, 20 + r).numpy() for r in range(world)]       # hand-off B: one per shard
+    qx, sfx = O.quantize_x(bits(x), idx1, KE, O.G16, sf_fill=0)
+    qw1, sfw1 = O.quantize_w(bits(w1), idx1, KE, O.G16, sf_fill=0)
+    return dict(M=M, H=H, NI=NI, N2=N2, KE=KE, qx=qx, sfx=sfx, qw1=qw1, sfw1=sfw1, alpha1=float(sx * s1), w2=w2, idx2=idx2,
+                local_idx=local_idx, shard=shard)
+
+
+def _handoff_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        P = _mlp_problem(world)
+        M, NI, KE = P["M"], P["NI"], P["KE"]
+        # column-parallel first linear on this rank's rows of W1 (scale tiles stay whole)
+        n0, n1 = tp.n_slices(NI, world)[rank]
+        b, sfb = tp.shard_n(torch.from_numpy(P["qw1"]), torch.from_numpy(P["sfw1"]), n0, n1)
+        yb, _ = O.gemm(P["qx"], b.numpy(), P["sfx"], sfb.numpy(), P["alpha1"])
+        y_local = torch.from_numpy(yb.view(np.int16)).view(torch.bfloat16)                      # bf16 [M, NI / world]
+        widths = [e - s_ for s_, e in tp.n_slices(NI, world)]
+        # ---- hand-off A: all-gather, quantise the full row replicated, slice K
+        y_full = tp.handoff_gather(y_local, widths)
+        scale_a, xs = _torch_gpu_scale_and_prescale(y_full, int(tp.absmax_word(y_full)))
+        qa, sfa = O.quantize_x(bits(xs), P["idx2"], KE, O.G16, sf_fill=0)
+        w2s, s2 = prescale(P["w2"])
+        qw2, sfw2 = O.quantize_w(bits(w2s), P["idx2"], KE, O.G16, sf_fill=0)
+        k0, k1 = tp.k_slices(NI + KE, world)[rank]
+        a_sh, sfa_sh = tp.shard_k(torch.from_numpy(qa), torch.from_numpy(sfa), k0, k1)
+        b_sh, sfb_sh = tp.shard_k(torch.from_numpy(qw2), torch.from_numpy(sfw2), k0, k1)
+        _, part = O.gemm(a_sh.numpy(), b_sh.numpy(), sfa_sh.numpy(), sfb_sh.numpy(), np.float32(scale_a) * np.float32(float(s2)))
+        out_a = torch.from_numpy(part)
+        dist.all_reduce(out_a, op=dist.ReduceOp.SUM)
+        # ---- hand-off B: only the abs-max word travels; shard-local reorder_index and residual channels
+        word = tp.handoff_local_scale(y_local)
+        scale_b, xs_l = _torch_gpu_scale_and_prescale(y_local, int(word))
+        lidx = P["local_idx"][rank]
+        ql, sfl = O.quantize_x(bits(xs_l), lidx, KE, O.G16, sf_fill=0)
+        w2_l = (P["w2"][:, n0:n1].float() / float(s2)).to(torch.bfloat16)                       # this rank's input channels, the layer's scale
+        qwl, sfwl = O.quantize_w(bits(w2_l.contiguous()), lidx, KE, O.G16, sf_fill=0)
+        _, part_b = O.gemm(ql, qwl, sfl, sfwl, np.float32(scale_b) * np.float32(float(s2)))
+        out_b = torch.from_numpy(part_b)
+        dist.all_reduce(out_b, op=dist.ReduceOp.SUM)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), y_local=bits(y_local), qa=qa, sfa=sfa, scale_a=scale_a, out_a=out_a.numpy(),
+                 word=int(word), ql=ql, sfl=sfl, scale_b=scale_b, out_b=out_b.numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_column_to_row_handoff_both_ways_against_the_unsharded_oracle(tmp_path, world):
+    port = _free_port()
+    mp.spawn(_handoff_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    P = _mlp_problem(world)
+    M, NI, KE = P["M"], P["NI"], P["KE"]
+    # unsharded reference: the whole layer pair through the oracle
+    yb, _ = O.gemm(P["qx"], P["qw1"], P["sfx"], P["sfw1"], P["alpha1"])
+    y = torch.from_numpy(yb.view(np.int16)).view(torch.bfloat16)
+    amax_bits = int(tp.absmax_word(y))
+    scale, xs = _torch_gpu_scale_and_prescale(y, amax_bits)
+    qa, sfa = O.quantize_x(bits(xs), P["idx2"], KE, O.G16, sf_fill=0)
+    w2s, s2 = prescale(P["w2"])
+    qw2, sfw2 = O.quantize_w(bits(w2s), P["idx2"], KE, O.G16, sf_fill=0)
+    _, want_a = O.gemm(qa, qw2, sfa, sfw2, np.float32(scale) * np.float32(float(s2)))
+    dense = (xs.float() * scale) @ P["w2"].float().t()
+    want_b = np.zeros_like(want_a)
+    for r in range(world):
+        g = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        n0, n1 = tp.n_slices(NI, world)[r]
+        assert np.array_equal(g["y_local"], bits(y[:, n0:n1]))
+        # A: EVERY rank holds the unsharded quantiser's bytes and scale
+        assert np.array_equal(g["qa"], qa) and np.array_equal(g["sfa"], sfa) and float(g["scale_a"]) == scale
+        assert np.allclose(g["out_a"], want_a, rtol=1e-12, atol=1e-12 * np.abs(want_a).max())
+        # B: the global abs-max word, and this rank's bytes == the unsharded quantiser on its column slice with the global scale
+        assert int(g["word"]) == amax_bits and float(g["scale_b"]) == scale
+        ql, sfl = O.quantize_x(bits(xs[:, n0:n1].contiguous()), P["local_idx"][r], KE, O.G16, sf_fill=0)
+        assert np.array_equal(g["ql"], ql) and np.array_equal(g["sfl"], sfl)
+        w2_l = (P["w2"][:, n0:n1].float() / float(s2)).to(torch.bfloat16)
+        qwl, sfwl = O.quantize_w(bits(w2_l.contiguous()), P["local_idx"][r], KE, O.G16, sf_fill=0)
+        want_b += O.gemm(ql, qwl, sfl, sfwl, np.float32(scale) * np.float32(float(s2)))[1]
+    g0 = np.load(os.path.join(str(tmp_path), "rank0.npz"))
+    assert np.allclose(g0["out_b"], want_b, rtol=1e-12, atol=1e-12 * np.abs(want_b).max())
+    # both are ARC-NVFP4 approximations of the dense layer of the same quality (fp4 weights: ~10 % of the output norm on uniform weights)
+    err_a = np.linalg.norm(want_a - dense.numpy()) / np.linalg.norm(dense.numpy())
+    err_b = np.linalg.norm(want_b - dense.numpy()) / np.linalg.norm(dense.numpy())
+    assert err_a < 0.2 and err_b < 0.2 and abs(err_a - err_b) < 0.02, (err_a, err_b)
+    assert tp.handoff_bytes_per_rank(M, NI, world, "gather") == (world - 1) * M * (NI // world) * 2
+    assert tp.handoff_bytes_per_rank(M, NI, world, "local_scale") == 4 * (world - 1)
