@@ -16,6 +16,16 @@
 
 #include "arcq_device.hpp"
 
+// Weight streams of the decode kernels: every byte is read ONCE per launch by ONE CU, so it is loaded with the non-temporal
+// policy (global_load ... nt).  Measured on MI355X against default-policy loads (tools/decode_stream_bench.py, HBM-cold): gate|up
+// 20.5 -> 19.2 us, N=14336 9.9 -> 9.3, down 13.3 -> 12.7, the 28-layer decode step 1758 -> 1842 tok/s.  -DARCQ_PLAIN_WEIGHT_LOADS
+// (make plain) builds the A-B library.  Never used for operands other workgroups re-read (the tile GEMM's panels).
+#ifdef ARCQ_PLAIN_WEIGHT_LOADS
+#define ARCQ_WLOAD(ptr) (*(ptr))
+#else
+#define ARCQ_WLOAD(ptr) __builtin_nontemporal_load(ptr)
+#endif
+
 namespace arcq {
 
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));

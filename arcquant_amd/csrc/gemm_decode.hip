@@ -147,11 +147,11 @@ __global__ __launch_bounds__(kDecThreads, kADw == 1 ? 4 : 2) void gemm_decode_ke
   // at the last item, so the ring's final refills re-read valid memory.
   auto issue_next = [&](DecodeRegs<kADw>& r) __attribute__((always_inline)) {
     const uint32_t koff = min(k_cur, k_last);
-    r.b0 = *reinterpret_cast<const u32x4*>(p.B + (size_t)(b_row0 + koff));
-    r.b1 = *reinterpret_cast<const u32x4*>(p.B + (size_t)(b_row1 + koff));
+    r.b0 = ARCQ_WLOAD(reinterpret_cast<const u32x4*>(p.B + (size_t)(b_row0 + koff)));
+    r.b1 = ARCQ_WLOAD(reinterpret_cast<const u32x4*>(p.B + (size_t)(b_row1 + koff)));
     const uint32_t so = min(sfb_row + sfb_cur, sfb_rowmax);
-    r.sb0 = *reinterpret_cast<const uint32_t*>(p.SFB + (size_t)so);
-    r.sb1 = *reinterpret_cast<const uint32_t*>(p.SFB + (size_t)so + 64);
+    r.sb0 = ARCQ_WLOAD(reinterpret_cast<const uint32_t*>(p.SFB + (size_t)so));
+    r.sb1 = ARCQ_WLOAD(reinterpret_cast<const uint32_t*>(p.SFB + (size_t)so + 64));
     const uint32_t akoff = min(ak_cur, ak_last), sao = min(sfa_cur, sfa_last);
     auto ld_a = [&](int i) { return *reinterpret_cast<const uint32_t*>(p.A + (size_t)(a_row[i] + akoff)); };
     auto ld_sa = [&](int i) { return *reinterpret_cast<const uint32_t*>(p.SFA + (size_t)(sfa_row[i] + sao)); };

@@ -110,9 +110,10 @@ __global__ __launch_bounds__(kRbThreads, 4) void gemm_rowblock_kernel(RowblockPa
   int issued = 0;
   auto issue = [&](RowblockRegs& r) __attribute__((always_inline)) {       // unpredicated; the cursor stops at the last pair
     const int i = min(issued, last);
-    r.b0 = *reinterpret_cast<const rb_u32x4*>(wp + (size_t)i * 2048);
-    r.b1 = *reinterpret_cast<const rb_u32x4*>(wp + (size_t)i * 2048 + 1024);
-    r.s = *reinterpret_cast<const uint32_t*>(sp + (size_t)i * 256);
+    // a weight byte is read once per launch by one CU: non-temporal loads (gemm_common.hpp)
+    r.b0 = ARCQ_WLOAD(reinterpret_cast<const rb_u32x4*>(wp + (size_t)i * 2048));
+    r.b1 = ARCQ_WLOAD(reinterpret_cast<const rb_u32x4*>(wp + (size_t)i * 2048 + 1024));
+    r.s = ARCQ_WLOAD(reinterpret_cast<const uint32_t*>(sp + (size_t)i * 256));
     ++issued;
   };
   RowblockRegs r0, r1, r2;

@@ -133,8 +133,12 @@ __global__ __launch_bounds__(kWaves * 64, 4) void gemm_skinny_kernel(SkinnyParam
   auto issue_next = [&](ItemRegs& r) {
     if (issued < nitems) {                                     // wave-uniform
       const uint32_t koff = min(k_cur, k_last);
-      r.b = *reinterpret_cast<const uint4*>(p.B + (size_t)(b_row + koff));
-      r.sb = *reinterpret_cast<const uint32_t*>(p.SFB + (size_t)min(sfb_row + sfb_cur, sfb_rowmax));
+      {
+        typedef uint32_t sk_u32x4 __attribute__((ext_vector_type(4)));
+        const sk_u32x4 wv = ARCQ_WLOAD(reinterpret_cast<const sk_u32x4*>(p.B + (size_t)(b_row + koff)));
+        r.b = make_uint4(wv.x, wv.y, wv.z, wv.w);
+      }
+      r.sb = ARCQ_WLOAD(reinterpret_cast<const uint32_t*>(p.SFB + (size_t)min(sfb_row + sfb_cur, sfb_rowmax)));
       if (a_loader) {
         r.a = *reinterpret_cast<const uint4*>(p.A + (size_t)(a_row + koff));
         r.sa = *reinterpret_cast<const uint16_t*>(p.SFA + (size_t)min(sfa_cur, sfa_last));

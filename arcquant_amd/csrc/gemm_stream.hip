@@ -252,9 +252,10 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
   const uint8_t* const wp = p.RW + ((size_t)rb0 * P + u0) * 2048 + lane * 16;
   const uint8_t* const sp = p.RSF + ((size_t)rb0 * P + u0) * 256 + lane * 4;
   auto load_unit = [&](StreamRegs& r, int i) __attribute__((always_inline)) {       // unit i of this wave's range
-    r.b0 = *reinterpret_cast<const st_u32x4*>(wp + (size_t)i * 2048);
-    r.b1 = *reinterpret_cast<const st_u32x4*>(wp + (size_t)i * 2048 + 1024);
-    r.s = *reinterpret_cast<const uint32_t*>(sp + (size_t)i * 256);
+    // a weight byte is read once per launch by one CU: non-temporal loads (gemm_common.hpp)
+    r.b0 = ARCQ_WLOAD(reinterpret_cast<const st_u32x4*>(wp + (size_t)i * 2048));
+    r.b1 = ARCQ_WLOAD(reinterpret_cast<const st_u32x4*>(wp + (size_t)i * 2048 + 1024));
+    r.s = ARCQ_WLOAD(reinterpret_cast<const uint32_t*>(sp + (size_t)i * 256));
   };
   const int ntasks = (n + kTask - 1) / kTask;
   int task_left = ntasks, done = 0;
