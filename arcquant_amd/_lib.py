@@ -52,6 +52,12 @@ SYMBOLS = {
     "arcq_silu_mul_quantize_x_dyn_slots": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _i32, _p]),
 }
 
+# include/arcq_harness.h: e2e-harness-only entry points (NOT the drop-in boundary)
+HARNESS_SYMBOLS = {
+    "arcq_harness_attn_workspace_bytes": (_i64, [_i64, _i64, _i64]),
+    "arcq_harness_attn_decode": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
+}
+
 _lib = None
 
 
@@ -69,7 +75,7 @@ def lib() -> ctypes.CDLL:
                 "There is no CPU fallback."
             )
         L = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SYMBOLS.items():
+        for name, (res, args) in list(SYMBOLS.items()) + list(HARNESS_SYMBOLS.items()):
             fn = getattr(L, name)          # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args

@@ -1,0 +1,204 @@
+// Decode attention of the END-TO-END HARNESS (arcquant_amd/e2e.py; SURVEY.md 8-f2: "attention stub"), NOT part of the drop-in
+// boundary: the reference's attention is flashinfer over an int4 paged KV cache (kernels/src/flashinfer.cu, model/kv_cache.py),
+// which stays out of scope (agemm.batch_decode_* raise NotImplementedError).  The harness keeps a dense bf16 cache and, for a
+// decode step (one query token per sequence), torch's SDPA / bmm need 45-48 us per layer for the 60 MB of K and V they read
+// (1.2 TB/s; tools/sdpa_decode_probe.py) -- 41 % of the measured Qwen2.5-7B full-cache decode step.  This is the streaming
+// form of that one call (flash-decoding): HBM-bound, bytes = 2 * B * H * T * 128 * 2.
+//
+//   attn_decode_partial: grid (B * H, S): workgroup (b, h, s) streams K then V of its slice of the sequence with fully
+//       coalesced 16-byte loads (a wave reads four 256-byte rows per instruction), scores and probabilities through LDS,
+//       fp32 throughout; the slice that holds the NEW token takes k/v from the fused q|k|v projection output and appends them
+//       to the cache on the way (replaces the harness's strided copy launch); leaves (max, sum, 128 accumulators) per slice
+//   attn_decode_combine: grid (B * H): merges the S slices (log-sum-exp) and writes bf16 [B, H * 128]
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "arcq_device.hpp"
+#include "arcq_internal.hpp"
+
+namespace arcq {
+
+constexpr int kAttnD = 128;            // head dimension (every model of benchmarks/benchmark_e2e_arc.py:26-77)
+constexpr int kAttnThreads = 256;
+constexpr int kAttnMaxChunk = 1024;    // positions per workgroup (LDS score buffer)
+
+struct AttnParams {
+  const uint16_t* qkv;    // bf16 [B, 3 * H * 128]: q | k | v of the current token (the fused projection's output)
+  uint16_t* kcache;       // bf16 [B, H, Tmax, 128]
+  uint16_t* vcache;
+  float* ws;              // [B * H, S, 130]: max, sum, 128 accumulators
+  uint16_t* out;          // bf16 [B, H * 128]
+  int B, H, Tmax, pos, S, chunk;
+  float scale;
+};
+
+__global__ __launch_bounds__(kAttnThreads) void attn_decode_partial(AttnParams p) {
+  __shared__ float sc[kAttnMaxChunk];
+  __shared__ float red[kAttnThreads / 64][kAttnD];
+  __shared__ float wred[8];
+  const int bh = blockIdx.x, s = blockIdx.y;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane >> 4, c = lane & 15;                  // row within a 4-row wave load, 16-byte column chunk
+  const int T = p.pos + 1;                                 // positions attended: the cache [0, pos) and the new token
+  const int t0 = s * p.chunk, t1 = min(T, t0 + p.chunk);
+  const size_t hidden = (size_t)p.H * kAttnD;
+  const uint16_t* qrow = p.qkv + (size_t)b * 3 * hidden + (size_t)h * kAttnD;
+  uint16_t* K = p.kcache + ((size_t)bh * p.Tmax) * kAttnD;
+  uint16_t* V = p.vcache + ((size_t)bh * p.Tmax) * kAttnD;
+
+  // the new token's k / v: append to the cache (one slice does it) -- the scores below read them from the projection output
+  if (t0 <= p.pos && p.pos < t1 && tid < 2 * kAttnD / 8) {
+    const int which = tid >> 4, cc = tid & 15;             // 0: k, 1: v
+    const uint4 d = *reinterpret_cast<const uint4*>(qrow + (1 + which) * hidden + cc * 8);
+    *reinterpret_cast<uint4*>((which ? V : K) + (size_t)p.pos * kAttnD + cc * 8) = d;
+  }
+  float q8[8];
+  {
+    const uint4 d = *reinterpret_cast<const uint4*>(qrow + c * 8);
+    const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      q8[2 * j] = bf16_bits_to_f32(w[j] & 0xffffu) * p.scale;
+      q8[2 * j + 1] = bf16_bits_to_f32(w[j] >> 16) * p.scale;
+    }
+  }
+  auto row_ptr = [&](const uint16_t* base, int which, int t) -> const uint16_t* {      // position t of K (which = 1) / V (2)
+    return t == p.pos ? qrow + which * hidden : base + (size_t)t * kAttnD;
+  };
+  // ---- pass 1: scores of this slice -> LDS; four rows per wave instruction, four instructions in flight
+  float mloc = -3.0e38f;
+  for (int tb = t0 + wave * 16; tb < t1; tb += (kAttnThreads / 64) * 16) {
+    uint4 kv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = min(tb + u * 4 + r, t1 - 1);
+      kv[u] = *reinterpret_cast<const uint4*>(row_ptr(K, 1, t) + c * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t w[4] = {kv[u].x, kv[u].y, kv[u].z, kv[u].w};
+      float d = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d += q8[2 * j] * bf16_bits_to_f32(w[j] & 0xffffu) + q8[2 * j + 1] * bf16_bits_to_f32(w[j] >> 16);
+#pragma unroll
+      for (int sh = 8; sh > 0; sh >>= 1) d += __shfl_xor(d, sh, 64);
+      const int t = tb + u * 4 + r;
+      if (t < t1) {
+        if (c == 0) sc[t - t0] = d;
+        mloc = fmaxf(mloc, d);
+      }
+    }
+  }
+#pragma unroll
+  for (int sh = 32; sh > 0; sh >>= 1) mloc = fmaxf(mloc, __shfl_xor(mloc, sh, 64));
+  if (lane == 0) wred[wave] = mloc;
+  __syncthreads();
+  const float m = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+  float lsum = 0.f;
+  for (int i = tid; i < t1 - t0; i += kAttnThreads) {
+    const float e = __expf(sc[i] - m);
+    sc[i] = e;
+    lsum += e;
+  }
+#pragma unroll
+  for (int sh = 32; sh > 0; sh >>= 1) lsum += __shfl_xor(lsum, sh, 64);
+  if (lane == 0) wred[4 + wave] = lsum;
+  __syncthreads();
+  const float l = wred[4] + wred[5] + wred[6] + wred[7];
+  // ---- pass 2: acc[d] = sum_t p[t] * V[t][d]
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int tb = t0 + wave * 16; tb < t1; tb += (kAttnThreads / 64) * 16) {
+    uint4 vv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = min(tb + u * 4 + r, t1 - 1);
+      vv[u] = *reinterpret_cast<const uint4*>(row_ptr(V, 2, t) + c * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = tb + u * 4 + r;
+      const float pt = t < t1 ? sc[t - t0] : 0.f;
+      const uint32_t w[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[2 * j] += pt * bf16_bits_to_f32(w[j] & 0xffffu);
+        acc[2 * j + 1] += pt * bf16_bits_to_f32(w[j] >> 16);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {                            // the four row groups of a wave hold the same columns
+    acc[j] += __shfl_xor(acc[j], 16, 64);
+    acc[j] += __shfl_xor(acc[j], 32, 64);
+  }
+  if (r == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[wave][c * 8 + j] = acc[j];
+  }
+  __syncthreads();
+  float* o = p.ws + ((size_t)bh * p.S + s) * (kAttnD + 2);
+  if (tid < kAttnD) o[2 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+  if (tid == 0) {
+    o[0] = m;
+    o[1] = l;
+  }
+}
+
+__global__ __launch_bounds__(kAttnD) void attn_decode_combine(AttnParams p) {
+  const int bh = blockIdx.x, d = threadIdx.x;
+  const float* w = p.ws + (size_t)bh * p.S * (kAttnD + 2);
+  const int T = p.pos + 1;
+  float M = -3.0e38f;
+  for (int s = 0; s < p.S; ++s)
+    if (s * p.chunk < T) M = fmaxf(M, w[s * (kAttnD + 2)]);
+  float L = 0.f, a = 0.f;
+  for (int s = 0; s < p.S; ++s) {
+    if (s * p.chunk >= T) break;
+    const float f = __expf(w[s * (kAttnD + 2)] - M);
+    L += w[s * (kAttnD + 2) + 1] * f;
+    a += w[s * (kAttnD + 2) + 2 + d] * f;
+  }
+  const int b = bh / p.H, h = bh - b * p.H;
+  p.out[(size_t)b * p.H * kAttnD + (size_t)h * kAttnD + d] = (uint16_t)f32_to_bf16_bits(a / L);
+}
+
+}  // namespace arcq
+
+using namespace arcq;
+
+extern "C" int64_t arcq_harness_attn_workspace_bytes(int64_t B, int64_t H, int64_t Tmax) {
+  if (B <= 0 || H <= 0 || Tmax <= 0) return 0;
+  const int64_t S = (Tmax + 255) / 256;
+  return B * H * S * (kAttnD + 2) * (int64_t)sizeof(float);
+}
+
+// HARNESS ONLY (see the header of this file).  qkv bf16 [B, 3 * H * 128] (q | k | v of ONE new token per sequence), caches bf16
+// [B, H, Tmax, 128]; appends k / v at position `pos` and writes softmax(q k^T / sqrt(128)) v over positions [0, pos] to `out`
+// (bf16 [B, H * 128]).  workspace >= arcq_harness_attn_workspace_bytes(B, H, Tmax).
+extern "C" int arcq_harness_attn_decode(const void* qkv, void* kcache, void* vcache, void* out, void* workspace, int64_t B, int64_t H, int64_t Tmax,
+                                        int64_t pos, void* stream) {
+  const char* who = "arcq_harness_attn_decode";
+  if (B <= 0 || H <= 0 || Tmax <= 0 || pos < 0 || pos >= Tmax) return fail(ARCQ_ERR_SHAPE, "%s: bad B / H / Tmax / pos", who);
+  if (!qkv || !kcache || !vcache || !out || !workspace) return fail(ARCQ_ERR_NULL, "%s: NULL pointer", who);
+  if ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(kcache) | reinterpret_cast<uintptr_t>(vcache)) & 15)
+    return fail(ARCQ_ERR_SHAPE, "%s: qkv and the caches must be 16-byte aligned", who);
+  AttnParams p;
+  p.qkv = (const uint16_t*)qkv; p.kcache = (uint16_t*)kcache; p.vcache = (uint16_t*)vcache; p.ws = (float*)workspace; p.out = (uint16_t*)out;
+  p.B = (int)B; p.H = (int)H; p.Tmax = (int)Tmax; p.pos = (int)pos;
+  // slices of >= 128 positions, enough of them to give every CU a workgroup, at most kAttnMaxChunk positions each; the slice
+  // count is fixed per Tmax (workspace layout), the slices beyond pos stay empty
+  const int T = (int)pos + 1;
+  int S = (int)((Tmax + 255) / 256);
+  int chunk = (T + S - 1) / S;
+  chunk = (chunk + 15) & ~15;
+  if (chunk > kAttnMaxChunk) return fail(ARCQ_ERR_UNSUPPORTED, "%s: more than %d positions per slice", who, kAttnMaxChunk);
+  p.S = S; p.chunk = chunk;
+  p.scale = 0.08838834764831845f;                           // 128^-0.5
+  const int live = (T + chunk - 1) / chunk;
+  hipLaunchKernelGGL(attn_decode_partial, dim3((unsigned)(B * H), (unsigned)live), dim3(kAttnThreads), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(attn_decode_combine, dim3((unsigned)(B * H)), dim3(kAttnD), 0, (hipStream_t)stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "%s: launch failed: %s", who, hipGetErrorString(e));
+  return ARCQ_OK;
+}

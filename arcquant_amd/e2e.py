@@ -99,7 +99,10 @@ class DecoderModel:
         # MI355X with tools/e2e_fuse_ab.py, the default is the fastest combination measured there
         import os
         self.fuse = set(filter(None, os.environ.get("ARCQ_E2E_FUSE", "qkv,o,gateup").split(",")))
-        self.decode_attention = os.environ.get("ARCQ_E2E_DECODE_ATTENTION", "sdpa")     # "sdpa" | "bmm" (torch glue, outside SURVEY 8)
+        # the decode step's attention over the bf16 cache (harness glue, outside SURVEY 8): "stream" = the harness's own streaming
+        # kernel (include/arcq_harness.h; it also appends k / v), "sdpa" / "bmm" = torch (45-48 us per layer at 1040 tokens)
+        self.decode_attention = os.environ.get("ARCQ_E2E_DECODE_ATTENTION", "stream" if fused else "sdpa")
+        self._attn_ws = None
         g = torch.Generator(device=device).manual_seed(0)
         h, it, ke = cfg.hidden_size, cfg.intermediate_size, cfg.select_num
         ab, mb = cfg.attention_bias, cfg.mlp_bias
@@ -157,25 +160,10 @@ class DecoderModel:
             else:
                 A, SFA = agemm.rmsnorm_quantize_x(hcur, L["ln1"], cfg.eps, self.idx_h, ke)
                 q, k, v = (self._ref_linear(L[n], A, SFA, L[n].scale) for n in ("q", "k", "v"))
-            q = q.reshape(bsz, q_len, nh, hd).transpose(1, 2)
-            if self.fused:      # k|v are adjacent columns of the fused projection: ONE strided copy appends both to the cache
-                L["kv"][:, :, :, pos:pos + q_len] = qkv[:, h:].reshape(bsz, q_len, 2, nh, hd).permute(2, 0, 3, 1, 4)
+            if self.fused and self.attention == "cache" and q_len == 1 and hd == 128 and self.decode_attention == "stream":
+                att = self._attn_decode_stream(qkv, L, pos)          # K|V append + attention over [0, pos]: the harness's own kernel
             else:
-                L["kc"][:, :, pos:pos + q_len] = k.reshape(bsz, q_len, nh, hd).transpose(1, 2)
-                L["vc"][:, :, pos:pos + q_len] = v.reshape(bsz, q_len, nh, hd).transpose(1, 2)
-            if self.attention == "cache" and q_len == 1 and self.decode_attention == "bmm":
-                # one query per sequence: attention is two batched GEMVs over the cache (torch.bmm = rocBLAS) around a softmax;
-                # the flash kernel SDPA picks here is built for long queries (53 us per layer for 60 MB of K/V: 1.1 TB/s)
-                kc, vc = L["kc"][:, :, :pos + 1], L["vc"][:, :, :pos + 1]
-                sc = torch.matmul(q, kc.transpose(2, 3)) * (hd ** -0.5)                      # [bsz, nh, 1, pos+1]
-                att = torch.matmul(torch.softmax(sc.float(), dim=-1).to(q.dtype), vc)
-            elif self.attention == "cache":
-                att = F.scaled_dot_product_attention(q, L["kc"][:, :, :pos + q_len], L["vc"][:, :, :pos + q_len],
-                                                     is_causal=(q_len > 1 and pos == 0))
-            else:
-                att = F.scaled_dot_product_attention(q, k.reshape(bsz, q_len, nh, hd).transpose(1, 2),
-                                                     v.reshape(bsz, q_len, nh, hd).transpose(1, 2), is_causal=q_len > 1)
-            att = att.transpose(1, 2).reshape(T, cfg.hidden_size)
+                att = self._attention_torch(L, q, k, v, qkv if self.fused else None, pos, bsz, q_len)
             # ---- output projection (+ residual)
             if self.fused:
                 O_ = L["o"]
@@ -223,6 +211,44 @@ class DecoderModel:
                 hcur = hcur + self._ref_linear(L["down"], qa, sfa, sa * L["down"].scale)
         hn = F.rms_norm(hcur.view(bsz, q_len, -1)[:, -1], (cfg.hidden_size,), self.norm, cfg.eps)
         return hn @ self.lm_head.t()
+
+    def _attention_torch(self, L, q, k, v, qkv, pos, bsz, q_len):
+        """KV append + attention with torch ops (prefill always; decode when the streaming kernel is switched off)."""
+        cfg = self.cfg
+        nh, hd, h = cfg.num_heads, cfg.hidden_size // cfg.num_heads, cfg.hidden_size
+        q = q.reshape(bsz, q_len, nh, hd).transpose(1, 2)
+        if qkv is not None:     # k|v are adjacent columns of the fused projection: ONE strided copy appends both to the cache
+            L["kv"][:, :, :, pos:pos + q_len] = qkv[:, h:].reshape(bsz, q_len, 2, nh, hd).permute(2, 0, 3, 1, 4)
+        else:
+            L["kc"][:, :, pos:pos + q_len] = k.reshape(bsz, q_len, nh, hd).transpose(1, 2)
+            L["vc"][:, :, pos:pos + q_len] = v.reshape(bsz, q_len, nh, hd).transpose(1, 2)
+        if self.attention == "cache" and q_len == 1 and self.decode_attention == "bmm":
+            kc, vc = L["kc"][:, :, :pos + 1], L["vc"][:, :, :pos + 1]
+            sc = torch.matmul(q, kc.transpose(2, 3)) * (hd ** -0.5)
+            att = torch.matmul(torch.softmax(sc.float(), dim=-1).to(q.dtype), vc)
+        elif self.attention == "cache":
+            att = F.scaled_dot_product_attention(q, L["kc"][:, :, :pos + q_len], L["vc"][:, :, :pos + q_len],
+                                                 is_causal=(q_len > 1 and pos == 0))
+        else:                   # benchmarks/modeling_arc.py:169-198: each sequence attends over the tokens of THIS call only
+            att = F.scaled_dot_product_attention(q, k.reshape(bsz, q_len, nh, hd).transpose(1, 2),
+                                                 v.reshape(bsz, q_len, nh, hd).transpose(1, 2), is_causal=q_len > 1)
+        return att.transpose(1, 2).reshape(bsz * q_len, h)
+
+    def _attn_decode_stream(self, qkv, L, pos):
+        """One decode step of attention over the dense bf16 cache with the harness kernel (include/arcq_harness.h): appends this
+        token's k / v at `pos` and attends over [0, pos]; fp32 math, bf16 out [batch, hidden]."""
+        from . import _lib
+        lib = _lib.lib()
+        bsz, nh = qkv.shape[0], self.cfg.num_heads
+        tmax = L["kc"].shape[2]
+        if self._attn_ws is None:
+            self._attn_ws = torch.empty(int(lib.arcq_harness_attn_workspace_bytes(bsz, nh, tmax)) // 4, dtype=torch.float32, device=qkv.device)
+        out = torch.empty((bsz, self.cfg.hidden_size), dtype=torch.bfloat16, device=qkv.device)
+        with torch.cuda.device(qkv.device):
+            st = lib.arcq_harness_attn_decode(qkv.data_ptr(), L["kc"].data_ptr(), L["vc"].data_ptr(), out.data_ptr(), self._attn_ws.data_ptr(),
+                                              bsz, nh, tmax, int(pos), torch.cuda.current_stream(qkv.device).cuda_stream)
+        _lib.check(st, "harness attn_decode")
+        return out
 
     @staticmethod
     def _ref_linear(lin, A, SFA, scale):

@@ -289,6 +289,11 @@ def bench_extra(args, device, rank):
         # harness (modeling_arc.py:169-198 attends over the tokens of the current call only: no KV read) and is NOT the headline.
         extra["qwen2.5-7b_decode_step_full_cache"] = bench_decode("qwen2.5-7b", batch=4, prefill=1024, steps=16, device=device, fused=True, attention="cache")
         torch.cuda.empty_cache()
+        os.environ["ARCQ_E2E_DECODE_ATTENTION"] = "sdpa"     # the same step with torch's SDPA as the decode attention (harness glue A-B)
+        extra["qwen2.5-7b_decode_step_full_cache_torch_sdpa_attention"] = bench_decode("qwen2.5-7b", batch=4, prefill=1024, steps=16, device=device,
+                                                                                         fused=True, attention="cache")
+        del os.environ["ARCQ_E2E_DECODE_ATTENTION"]
+        torch.cuda.empty_cache()
         extra["qwen2.5-7b_decode_step_current_token_attention_harness_quirk"] = bench_decode("qwen2.5-7b", batch=4, prefill=1024, steps=16, device=device,
                                                                                                fused=True, attention="current")
         torch.cuda.empty_cache()

@@ -1,0 +1,32 @@
+/*
+ * arcq_harness.h -- entry points used ONLY by this repository's end-to-end harness (arcquant_amd/e2e.py).
+ *
+ * NOT part of the drop-in boundary (that is include/arcq.h): nothing in the reference binds these.  The reference's
+ * attention is flashinfer over an int4 paged KV cache (kernels/src/flashinfer.cu, bindings.cpp:576-581, model/kv_cache.py),
+ * which is out of scope here -- `agemm.batch_decode_*` / `init_kv_*` / `append_kv_*` stay NotImplementedError stubs.  The
+ * harness needs SOME attention between the ARC-NVFP4 linears to time a decoder step; it uses torch SDPA for prefill and, for
+ * the one-token decode step over its dense bf16 cache, the streaming kernel below (torch's SDPA / bmm take 45-48 us per layer
+ * for the 60 MB they read; this takes what the bytes take).
+ */
+#ifndef ARCQ_HARNESS_H_
+#define ARCQ_HARNESS_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* bytes of fp32 scratch for arcq_harness_attn_decode at this cache size */
+int64_t arcq_harness_attn_workspace_bytes(int64_t B, int64_t H, int64_t Tmax);
+
+/* One decode step of attention, head dimension 128: qkv = bf16 [B, 3*H*128] (q | k | v of the ONE new token per sequence, the
+ * fused projection's output), kcache / vcache = bf16 [B, H, Tmax, 128].  Appends k / v at position `pos`, then
+ * out[b, h*128 + d] = softmax(q k^T / sqrt(128)) v over positions [0, pos] (fp32 math, bf16 result).  Two launches on `stream`. */
+int arcq_harness_attn_decode(const void *qkv, void *kcache, void *vcache, void *out, void *workspace, int64_t B, int64_t H,
+                             int64_t Tmax, int64_t pos, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARCQ_HARNESS_H_ */

@@ -19,6 +19,10 @@ def _declared_symbols():
 
 def test_header_and_binding_table_agree():
     assert _declared_symbols() == sorted(_lib.SYMBOLS)
+    # the harness-only header (not the drop-in boundary) and its binding table
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "arcq_harness.h")).read(), flags=re.S)
+    assert sorted(set(re.findall(r"\b(arcq_[a-z0-9_]+)\s*\(", text))) == sorted(_lib.HARNESS_SYMBOLS)
+    assert not set(_lib.HARNESS_SYMBOLS) & set(_lib.SYMBOLS)
 
 
 def test_library_exports_every_declared_symbol():

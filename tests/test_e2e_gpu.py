@@ -139,3 +139,33 @@ def test_fused_decoder_layer_matches_the_oracle_stage_by_stage():
         # the chain above IS what forward() runs
         hn = F.rms_norm(h3.view(bsz, q_len, -1)[:, -1], (h,), model.norm, cfg.eps)
         assert torch.equal(hn @ model.lm_head.t(), logits)
+
+
+def test_harness_decode_attention_kernel_matches_torch_sdpa():
+    """The harness's streaming decode attention (include/arcq_harness.h; NOT part of the drop-in boundary) against torch on the
+    same dense bf16 cache: appends k / v at `pos` exactly as the strided copy does and attends over [0, pos]; fp32 math here
+    against flash attention's bf16 P: agreement to bf16 rounding.  Positions cover one slice, several slices, slice
+    boundaries and the last cache slot."""
+    import torch.nn.functional as F
+    e2e, _ = _toy()
+    cfg = e2e.ModelConfig("toyattn", num_layers=1, num_heads=4, hidden_size=512, intermediate_size=1024, vocab_size=64)
+    dev = torch.device("cuda:0")
+    bsz, tmax = 3, 1100
+    model = e2e.DecoderModel(cfg, bsz, tmax, dev, fused=True, attention="cache")
+    L = model.layers[0]
+    g = torch.Generator(device=dev).manual_seed(3)
+    nh, hd, h = 4, 128, 512
+    for pos in (0, 1, 15, 16, 255, 256, 700, 1039, tmax - 1):
+        L["kv"].copy_(torch.randn(L["kv"].shape, generator=g, device=dev).to(torch.bfloat16))
+        before = L["kv"].clone()
+        qkv = torch.randn(bsz, 3 * h, generator=g, device=dev).to(torch.bfloat16)
+        got = model._attn_decode_stream(qkv, L, pos)
+        # the append: only position `pos` of both caches changed, to this token's k / v
+        want_kv = before.clone()
+        want_kv[:, :, :, pos:pos + 1] = qkv[:, h:].reshape(bsz, 1, 2, nh, hd).permute(2, 0, 3, 1, 4)
+        assert torch.equal(L["kv"], want_kv), pos
+        q = qkv[:, :h].reshape(bsz, 1, nh, hd).transpose(1, 2)
+        want = F.scaled_dot_product_attention(q.float(), L["kc"][:, :, :pos + 1].float(), L["vc"][:, :, :pos + 1].float())
+        want = want.transpose(1, 2).reshape(bsz, h)
+        err = float((got.float() - want).abs().max())
+        assert err <= 2.0 ** -7 * float(want.abs().max()) + 1e-3, (pos, err)
