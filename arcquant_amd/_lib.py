@@ -47,7 +47,7 @@ SYMBOLS = {
     "arcq_gemm_nvfp4_repacked_silu_absmax": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f32, _p, _p]),
     "arcq_linear_fused_supported": (_i32, [_i32, _i64, _i64, _i64, _i64]),
     "arcq_linear_rmsnorm_repacked": (_i32, [_p, _p, _f32, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _f32, _p, _p, _p, _i32, _p]),
-    "arcq_linear_rmsnorm_silu_repacked": (_i32, [_p, _p, _f32, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _f32, _p, _p, _p]),
+    "arcq_linear_rmsnorm_silu_repacked": (_i32, [_p, _p, _f32, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _f32, _p, _p, _p, _p]),
     "arcq_linear_dynamic_repacked": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i32, _f32, _p, _p, _i32, _p]),
     "arcq_silu_mul_quantize_x_dyn_slots": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _i32, _p]),
 }

@@ -177,14 +177,28 @@ def absmax_scale(X: torch.Tensor) -> torch.Tensor:
 _dyn_state = {}
 
 
-def _quantize_dynamic(entry: str, who: str, X: torch.Tensor, KQ: int, reorder_index: torch.Tensor, KE: int, variant, slots=None, layout=None):
-    _need(reorder_index, torch.int16, "reorder_index", 1)
+class _NoIndex:
+    # reorder_index=None (arcq_quantize_x_dyn_slots only): X is already in reordered channel order, NULL at the C-ABI
+    @staticmethod
+    def data_ptr():
+        return None
+
+
+def _quantize_dynamic(entry: str, who: str, X: torch.Tensor, KQ: int, reorder_index, KE: int, variant, slots=None, layout=None):
     M = X.shape[0]
     KE = int(KE)
     K = KQ + KE
     if variant is None:
         variant = variant_for_kq(KQ)
-    if KQ % 64 or KE % 64 or KE < 0 or KE > KQ or reorder_index.numel() != KQ:
+    if reorder_index is None:
+        if entry != "arcq_quantize_x_dyn_slots":
+            raise RuntimeError(f"Value error in {who}: reorder_index=None needs absmax_slots")
+        if not X.is_contiguous():
+            raise RuntimeError(f"Value error in {who}: X must be contiguous")
+        reorder_index = _NoIndex
+    else:
+        _need(reorder_index, torch.int16, "reorder_index", 1)
+    if KQ % 64 or KE % 64 or KE < 0 or KE > KQ or (reorder_index is not _NoIndex and reorder_index.numel() != KQ):
         raise RuntimeError(f"Value error in {who}: KQ={KQ}, KE={KE} is not valid")
     dev = X.device
     key = (dev, _stream(X))                # scratch of the abs-max pass: one per device and stream (include/arcq.h)
@@ -328,7 +342,9 @@ def matmul_silu_mul(A: torch.Tensor, B: torch.Tensor, SFA: torch.Tensor, SFB: to
 def reorder_quantize_x_dynamic(X: torch.Tensor, reorder_index: torch.Tensor, KE: int, variant=None, absmax_slots=None):
     """Extension: ``NVFP4_reorder_quantize_x`` (model/qLlamaLayer.py:73-77) without a host sync, in ONE launch
     for decode-sized inputs (<= 256 KB) and two otherwise: returns (QX, SFX, scale) with ``scale = max|X|/2688`` a 0-dim
-    fp32 device tensor and (QX, SFX) byte-identical to ``reorder_quantize_x(X / scale, reorder_index, KE)``."""
+    fp32 device tensor and (QX, SFX) byte-identical to ``reorder_quantize_x(X / scale, reorder_index, KE)``.
+    ``reorder_index=None`` (with ``absmax_slots``): X is ALREADY in reordered channel order (``rmsnorm_matmul_repacked_silu(...,
+    act_scatter_index=)`` stored it so) -- same bytes as the natural-order tensor with the index, without the gather."""
     _need(X, torch.bfloat16, "X", 2)
     if absmax_slots is not None:           # max|X| already known per workgroup (matmul_silu_mul): one launch for any size
         _need(absmax_slots, torch.int32, "absmax_slots", 1)
@@ -464,11 +480,15 @@ def rmsnorm_matmul_repacked(X: torch.Tensor, W: torch.Tensor, eps: float, reorde
 
 
 def rmsnorm_matmul_repacked_silu(X: torch.Tensor, W: torch.Tensor, eps: float, reorder_index: torch.Tensor, KE: int, RW: torch.Tensor,
-                                 RSF: torch.Tensor, scale, N: int, *, scale_host: float = 1.0, variant=None, bias=None):
+                                 RSF: torch.Tensor, scale, N: int, *, scale_host: float = 1.0, variant=None, bias=None,
+                                 act_scatter_index=None):
     """Extension for decode, the MLP's first half in ONE launch: RMSNorm + quantise (prologue), gate|up GEMM over a repacked weight
     whose ROWS INTERLEAVE gate and up, ``act_fn(gate) * up`` (SiLU, model/qLlamaLayer.py:417) in the epilogue.  Returns
     ``(act bf16 [M, N/2], absmax_slots int32 [ceil(N/16)])``; ``act`` equals ``F.silu(y[:, 0::2]) * y[:, 1::2]`` of
-    ``y = rmsnorm_matmul_repacked(...)`` bit for bit and the slots let ``dynamic_matmul_repacked`` skip its abs-max pass."""
+    ``y = rmsnorm_matmul_repacked(...)`` bit for bit and the slots let ``dynamic_matmul_repacked`` skip its abs-max pass.
+    ``act_scatter_index`` (int16 [N/2], a permutation): activation j goes to column ``act_scatter_index[j]``; with the inverse of
+    the down projection's reorder_index the result is ``act[:, reorder_index]`` and the consumer quantises it with
+    ``reorder_quantize_x_dynamic(act, None, KE, absmax_slots=slots)``."""
     M, KQ, KE, N, variant = _fused_common("rmsnorm_matmul_repacked_silu", X, reorder_index, RW, RSF, N, KE, variant)
     _need(W, torch.bfloat16, "W", 1)
     if W.numel() != KQ or N % 4 or not fused_supported(SRC_RMSNORM, M, N, KQ, KE):
@@ -484,7 +504,8 @@ def rmsnorm_matmul_repacked_silu(X: torch.Tensor, W: torch.Tensor, eps: float, r
         st = _lib.lib().arcq_linear_rmsnorm_silu_repacked(X.data_ptr(), W.data_ptr(), float(eps), reorder_index.data_ptr(), RW.data_ptr(),
                                                           RSF.data_ptr(), act.data_ptr(), slots.data_ptr(), M, N, KQ, KE, variant, alpha_host,
                                                           alpha_dev.data_ptr() if alpha_dev is not None else None,
-                                                          _opt(bias, torch.bfloat16, "bias", (N,)), _stream(X))
+                                                          _opt(bias, torch.bfloat16, "bias", (N,)),
+                                                          _opt(act_scatter_index, torch.int16, "act_scatter_index", (N // 2,)), _stream(X))
     _lib.check(st, "rmsnorm_matmul_repacked_silu")
     return act, slots
 

@@ -78,6 +78,7 @@ struct FusedArgs {
   const uint8_t* RSF;
   void* D;
   uint32_t* out_slots;
+  const int16_t* act_scatter; // silu_act: ACT[m][act_scatter[j]] = activation j (NULL: ACT[m][j]); a permutation of 0 .. N/2-1
   int M, N, KQ, KE, variant;
   float alpha_host;
   const float* alpha_dev;

@@ -268,14 +268,17 @@ int arcq_linear_rmsnorm_repacked(const void* X, const void* Wn, float eps, const
 
 int arcq_linear_rmsnorm_silu_repacked(const void* X, const void* Wn, float eps, const int16_t* reorder_index, const uint8_t* RW,
                                       const uint8_t* RSF, void* ACT, uint32_t* absmax_slots, int64_t M, int64_t N, int64_t KQ, int64_t KE,
-                                      int variant, float alpha_host, const float* alpha_dev, const void* bias, void* stream) {
+                                      int variant, float alpha_host, const float* alpha_dev, const void* bias, const int16_t* act_scatter_index,
+                                      void* stream) {
   const char* who = "arcq_linear_rmsnorm_silu_repacked";
   const int rc = fused_common_checks(who, X, reorder_index, RW, RSF, ACT, M, N, KQ, KE, variant, ARCQ_OUT_BF16);
   if (rc != ARCQ_OK) return rc < 0 ? rc : ARCQ_OK;
   if (N % 4) return fail(ARCQ_ERR_SHAPE, "%s: N %% 4 != 0 (interleaved gate|up rows)", who);
   if (!Wn || !absmax_slots) return fail(ARCQ_ERR_NULL, "%s: NULL norm weight / absmax_slots", who);
   if ((reinterpret_cast<uintptr_t>(Wn) & 15) || (reinterpret_cast<uintptr_t>(absmax_slots) & 3)) return fail(ARCQ_ERR_SHAPE, "%s: misaligned norm weight / absmax_slots", who);
+  if (reinterpret_cast<uintptr_t>(act_scatter_index) & 3) return fail(ARCQ_ERR_SHAPE, "%s: misaligned act_scatter_index", who);
   FusedArgs f{};
+  f.act_scatter = act_scatter_index;
   f.kind = ARCQ_SRC_RMSNORM; f.silu_act = 1; f.X = (const uint16_t*)X; f.Wn = (const uint16_t*)Wn; f.eps = eps; f.idx = reorder_index;
   f.RW = RW; f.RSF = RSF; f.D = ACT; f.out_slots = absmax_slots; f.M = (int)M; f.N = (int)N; f.KQ = (int)KQ; f.KE = (int)KE; f.variant = variant;
   f.alpha_host = alpha_host; f.alpha_dev = alpha_dev; f.bias = (const uint16_t*)bias; f.out_dtype = ARCQ_OUT_BF16;

@@ -90,6 +90,7 @@ struct StreamParams {
   const uint16_t* bias;
   const uint16_t* residual;
   uint32_t* out_slots;        // kOutSilu*: one word per row block
+  const int16_t* act_scatter; // kOutSiluAct: output column of activation j (NULL: j)
   int M, N, K;
   float alpha_host;
   int out_dtype;
@@ -539,7 +540,14 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
         }
         const uint32_t a0 = silu_mul_bf16(y[0], y[1]);
         const uint32_t a1 = silu_mul_bf16(y[2], y[3]);
-        *reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(p.D) + ((size_t)rl * (p.N >> 1) + (n0 >> 1))) = a0 | (a1 << 16);
+        uint16_t* arow = reinterpret_cast<uint16_t*>(p.D) + (size_t)rl * (p.N >> 1);
+        if (p.act_scatter) {                                // the consumer's reorder_index applied here: it then reads contiguous groups
+          const uint32_t jj = *reinterpret_cast<const uint32_t*>(p.act_scatter + (n0 >> 1));
+          arow[jj & 0xffffu] = (uint16_t)a0;
+          arow[jj >> 16] = (uint16_t)a1;
+        } else {
+          *reinterpret_cast<uint32_t*>(arow + (n0 >> 1)) = a0 | (a1 << 16);
+        }
         mx = max(a0 & 0x7fffu, a1 & 0x7fffu);
       }
 #pragma unroll
@@ -670,7 +678,7 @@ int gemm_fused(const FusedArgs& f, hipStream_t stream) {
   StreamParams p;
   fill_common(p, g, a, f.RW, f.RSF);
   p.X = f.X; p.Wn = f.Wn; p.idx = f.idx; p.in_slots = f.in_slots; p.n_in_slots = f.n_in_slots; p.scale_out = f.scale_out;
-  p.eps = f.eps; p.KQ = f.KQ; p.KE = f.KE;
+  p.eps = f.eps; p.KQ = f.KQ; p.KE = f.KE; p.act_scatter = f.act_scatter;
   if (f.kind == kSrcRms) {
     if (f.silu_act) return launch_stream_variant<kSrcRms, kOutSiluAct>(p, g, f.variant, stream, who);
     return launch_stream_variant<kSrcRms, kOutPlain>(p, g, f.variant, stream, who);

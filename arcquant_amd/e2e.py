@@ -122,6 +122,8 @@ class DecoderModel:
                     L[name].repack()
         self.idx_h = torch.arange(h, dtype=torch.int16, device=device)
         self.idx_i = torch.arange(it, dtype=torch.int16, device=device)
+        self.inv_idx_i = torch.argsort(self.idx_i.long()).to(torch.int16)     # act_scatter_index of the gate|up epilogue
+        self.act_scatter = os.environ.get("ARCQ_E2E_ACT_SCATTER", "1") == "1"
         self.norm = torch.ones(h, dtype=torch.bfloat16, device=device)
         self.lm_head = (torch.randn(cfg.vocab_size, h, generator=g, device=device) * 0.02).to(torch.bfloat16)
         self.embed = (torch.randn(cfg.vocab_size, h, generator=g, device=device) * 0.02).to(torch.bfloat16)
@@ -181,7 +183,15 @@ class DecoderModel:
                 slots = None
                 if "gateup" in self.fuse and Gt.RW is not None and agemm.fused_supported(agemm.SRC_RMSNORM, T, Gt.out_f, h, ke):
                     # decode: RMSNorm + quantise + gate|up GEMM + bias + SiLU*up + abs-max words in ONE launch
-                    act, slots = agemm.rmsnorm_matmul_repacked_silu(hcur, L["ln2"], cfg.eps, self.idx_h, ke, Gt.RW, Gt.RSF, Gt.scale, Gt.out_f, bias=Gt.bias)
+                    # "scatter": its epilogue stores the activation in the DOWN projection's channel order, the quantiser below then
+                    # reads contiguous groups (reorder_index=None) instead of staging + gathering each row
+                    scatter = self.inv_idx_i if self.act_scatter and not (("down" in self.fuse or self.fused_down)) else None
+                    act, slots = agemm.rmsnorm_matmul_repacked_silu(hcur, L["ln2"], cfg.eps, self.idx_h, ke, Gt.RW, Gt.RSF, Gt.scale, Gt.out_f, bias=Gt.bias,
+                                                                    act_scatter_index=scatter)
+                    if scatter is not None:
+                        qa, sfa, sa = agemm.reorder_quantize_x_dynamic(act, None, ke, absmax_slots=slots)
+                        hcur = D_.matmul(qa, sfa, sa, scale_host=D_.scale_f, residual=hcur)
+                        continue
                 else:
                     A, SFA = agemm.rmsnorm_quantize_x(hcur, L["ln2"], cfg.eps, self.idx_h, ke)
                     if T > 16:      # prefill: act_fn(gate) * up and its abs-max in the tile GEMM's epilogue

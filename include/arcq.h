@@ -151,7 +151,9 @@ int64_t arcq_gemm_silu_mul_slots(int64_t M, int64_t N, int64_t K);
 int arcq_gemm_nvfp4_silu_mul(const uint8_t *A, const uint8_t *B, const uint8_t *SFA, const uint8_t *SFB, void *ACT,
                              uint32_t *absmax_slots, int64_t M, int64_t N, int64_t K, float alpha_host,
                              const float *alpha_dev, const void *bias, void *stream);   /* bias: optional bf16 [N], rows interleaved as B's */
-/* arcq_quantize_x_dyn with max|X| taken from `nslots` precomputed words instead of an abs-max pass. */
+/* arcq_quantize_x_dyn with max|X| taken from `nslots` precomputed words instead of an abs-max pass.
+ * reorder_index == NULL: X is already in reordered channel order (identity permutation; see act_scatter_index of
+ * arcq_linear_rmsnorm_silu_repacked) -- no gather, same bytes. */
 int arcq_quantize_x_dyn_slots(const void *X, const int16_t *reorder_index, uint8_t *QX, uint8_t *SFX, float *scale_out,
                               const uint32_t *absmax_slots, int64_t nslots, int64_t M, int64_t KQ, int64_t KE,
                               int variant, void *stream);
@@ -216,7 +218,12 @@ int arcq_linear_rmsnorm_repacked(const void *X, const void *Wn, float eps, const
 int arcq_linear_rmsnorm_silu_repacked(const void *X, const void *Wn, float eps, const int16_t *reorder_index, const uint8_t *RW,
                                       const uint8_t *RSF, void *ACT, uint32_t *absmax_slots, int64_t M, int64_t N, int64_t KQ,
                                       int64_t KE, int variant, float alpha_host, const float *alpha_dev, const void *bias,
-                                      void *stream);   /* bias: optional bf16 [N], interleaved (g0, u0, g1, u1, ...) like the rows */
+                                      const int16_t *act_scatter_index, void *stream);
+/* bias: optional bf16 [N], interleaved (g0, u0, g1, u1, ...) like the rows.
+ * act_scatter_index: optional int16 [N/2], a permutation (not checked): activation j is stored at ACT[m][act_scatter_index[j]].
+ * With act_scatter_index = the inverse of the consumer's reorder_index, ACT is already in reordered channel order and
+ * arcq_quantize_x_dyn_slots(ACT, reorder_index = NULL, ...) yields the same bytes as quantising the natural-order
+ * activation with that reorder_index. */
 /* scale = max|X| / 2688 (from absmax_slots[0..nslots) when given, else computed from X; written to scale_out[0] if not NULL);
  * D = alpha_host * scale * matmul(quantize_x(bf16(X / scale), reorder_index, KE), W) (+ bias) (+ residual): the reference's
  * NVFP4_reorder_quantize_x + QLinearLayer.forward with alpha_host = the weight's per-tensor scale. */

@@ -779,3 +779,42 @@ def test_fused_mlp_pair_equals_the_separate_launches(M, IT, KQ):
     assert float(got_scale) == float(sa) and torch.equal(got, want)
     got2, _ = ag.dynamic_matmul_repacked(act, idx_i, KE, RWd, RSFd, float(sd), Nd, residual=res)       # abs-max recomputed in the kernel
     assert torch.equal(got2, want)
+
+
+@pytest.mark.parametrize("M,IT,KQ,variant", [(4, 18944, 3584, None), (1, 1024, 2048, 0), (7, 1536, 2048, 1), (16, 320, 2048, None)])
+def test_gateup_epilogue_scatter_plus_contiguous_quantiser_equals_the_gather(M, IT, KQ, variant):
+    """act_scatter_index = inverse of the down projection's reorder_index: the gate|up epilogue stores act[:, reorder_index], and
+    reorder_quantize_x_dynamic(reorder_index=None) on it gives the bytes the gathering quantiser gives on the natural-order
+    activation -- codes, every swizzled scale byte (poisoned buffers are not used here: both sides come from torch.empty, so only
+    the used bytes are compared) and the per-tensor scale; both variants, residual channels included."""
+    ag = _agemm()
+    KE, N = 64, 2 * IT
+    g = torch.Generator().manual_seed(IT + M)
+    x = outlier_activations(M, KQ, 77 + M).to(DEV)
+    wn = (torch.rand(KQ, generator=g) + 0.5).to(torch.bfloat16).to(DEV)
+    wgu, sgu = prescale((torch.rand(N, KQ, generator=g) * 2 - 1.0).to(torch.bfloat16))
+    bias = (torch.randn(N, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+    idx = random_perm(KQ, 3).to(DEV)
+    RWg, RSFg = ag.repack_w(*ag.reorder_quantize_w(wgu.to(DEV), idx, KE))
+    alpha = float(sgu) * 3e-3
+    idx_i = random_perm(IT, 5).to(DEV)
+    inv = torch.argsort(idx_i.long()).to(torch.int16)
+    act, slots = ag.rmsnorm_matmul_repacked_silu(x, wn, 1e-6, idx, KE, RWg, RSFg, alpha, N, bias=bias)
+    act_s, slots_s = ag.rmsnorm_matmul_repacked_silu(x, wn, 1e-6, idx, KE, RWg, RSFg, alpha, N, bias=bias, act_scatter_index=inv)
+    assert torch.equal(act_s, act[:, idx_i.long()]) and torch.equal(slots_s, slots)
+    q0, sf0, s0 = ag.reorder_quantize_x_dynamic(act, idx_i, KE, variant=variant, absmax_slots=slots)
+    q1, sf1, s1 = ag.reorder_quantize_x_dynamic(act_s, None, KE, variant=variant, absmax_slots=slots_s)
+    assert float(s0) == float(s1) and torch.equal(q0, q1)
+    v = ag.variant_for_kq(IT) if variant is None else variant
+    want_q, want_sf = O.quantize_x(bits(ag_div(act, s0).cpu()), idx_i.cpu().numpy(), KE, v, sf_fill=0xEE)
+    assert np.array_equal(q1.cpu().numpy(), want_q)                                       # ... and the CPU oracle's bytes
+    used = want_sf != 0xEE
+    got0, got1 = sf0.cpu().numpy(), sf1.cpu().numpy()
+    assert np.array_equal(got0[used], got1[used]) and np.array_equal(got1[used], want_sf[used])
+    with pytest.raises(RuntimeError):
+        ag.reorder_quantize_x_dynamic(act_s, None, KE)                                   # identity order needs the abs-max words
+
+
+def ag_div(x, scale):
+    """torch's GPU `x / scale` for a bf16 tensor and a 0-dim fp32 scale (model/qLlamaLayer.py:74-76)."""
+    return x / scale
