@@ -508,9 +508,11 @@ def main():
                      "frac_of_fp4_peak": round(achieved / PEAK_FP4_TFLOPS, 4),
                      "note": "NVFP4 (ue4m3 scale per 16) has no exact mapping onto gfx950's E8M0-per-32 scaled fp4 MFMA; the exact "
                              "contraction runs on fp16 MFMA, so `peak` is the dense fp16/bf16 rate; frac_of_fp4_peak is the "
-                             "north-star denominator.  Under sustained load the socket power limit sets the clock (this kernel "
-                             "~2.19 GHz, the fp16 library GEMM ~1.73 GHz at ~1.35 kW, profiles/r01f_clocks_power_under_load.txt): "
-                             "`peak` assumes 2.4 GHz, extra.gemm_4096.fp16_rocblas_TFLOPs is what the vendor GEMM sustains beside it"},
+                             "north-star denominator.  In-kernel clock stamps (s_memtime / s_memrealtime around the K loop, "
+                             "profiles/r02_tile_gemm_in_kernel_clock.jsonl): the K loop runs at 2.07 GHz under sustained load, not the "
+                             "2.4 GHz `peak` assumes, with the matrix pipe busy 72.6 % of it; the K loop is 88.7 of the ~103 us launch "
+                             "(the rest: first loads + the 33.5 MB store burst at one tile per CU); "
+                             "extra.gemm_4096.fp16_rocblas_TFLOPs is what the vendor fp16 GEMM sustains beside it in the same state"},
     }
     if rank == 0 and world == 1:
         if not args.no_cpu:
