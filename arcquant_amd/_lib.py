@@ -56,6 +56,7 @@ SYMBOLS = {
 HARNESS_SYMBOLS = {
     "arcq_harness_attn_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "arcq_harness_attn_decode": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
+    "arcq_harness_attn_decode_window": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p]),
 }
 
 _lib = None

@@ -28,7 +28,7 @@ struct AttnParams {
   uint16_t* vcache;
   float* ws;              // [B * H, S, 130]: max, sum, 128 accumulators
   uint16_t* out;          // bf16 [B, H * 128]
-  int B, H, Tmax, pos, S, chunk;
+  int B, H, Tmax, pos, first, S, chunk;     // positions attended: [first, pos]
   float scale;
 };
 
@@ -40,8 +40,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_decode_partial(AttnParams p
   const int b = bh / p.H, h = bh - b * p.H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane >> 4, c = lane & 15;                  // row within a 4-row wave load, 16-byte column chunk
-  const int T = p.pos + 1;                                 // positions attended: the cache [0, pos) and the new token
-  const int t0 = s * p.chunk, t1 = min(T, t0 + p.chunk);
+  const int T = p.pos + 1;                                 // positions attended: the cache [first, pos) and the new token
+  const int t0 = p.first + s * p.chunk, t1 = min(T, t0 + p.chunk);
   const size_t hidden = (size_t)p.H * kAttnD;
   const uint16_t* qrow = p.qkv + (size_t)b * 3 * hidden + (size_t)h * kAttnD;
   uint16_t* K = p.kcache + ((size_t)bh * p.Tmax) * kAttnD;
@@ -137,6 +137,10 @@ __global__ __launch_bounds__(kAttnThreads) void attn_decode_partial(AttnParams p
     for (int j = 0; j < 8; ++j) red[wave][c * 8 + j] = acc[j];
   }
   __syncthreads();
+  if (gridDim.y == 1) {                                    // one slice: nothing to combine, no second launch
+    if (tid < kAttnD) p.out[(size_t)b * hidden + (size_t)h * kAttnD + tid] = (uint16_t)f32_to_bf16_bits((red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]) / l);
+    return;
+  }
   float* o = p.ws + ((size_t)bh * p.S + s) * (kAttnD + 2);
   if (tid < kAttnD) o[2 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
   if (tid == 0) {
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_decode_partial(AttnParams p
 __global__ __launch_bounds__(kAttnD) void attn_decode_combine(AttnParams p) {
   const int bh = blockIdx.x, d = threadIdx.x;
   const float* w = p.ws + (size_t)bh * p.S * (kAttnD + 2);
-  const int T = p.pos + 1;
+  const int T = p.pos + 1 - p.first;
   float M = -3.0e38f;
   for (int s = 0; s < p.S; ++s)
     if (s * p.chunk < T) M = fmaxf(M, w[s * (kAttnD + 2)]);
@@ -176,19 +180,27 @@ extern "C" int64_t arcq_harness_attn_workspace_bytes(int64_t B, int64_t H, int64
 // HARNESS ONLY (see the header of this file).  qkv bf16 [B, 3 * H * 128] (q | k | v of ONE new token per sequence), caches bf16
 // [B, H, Tmax, 128]; appends k / v at position `pos` and writes softmax(q k^T / sqrt(128)) v over positions [0, pos] to `out`
 // (bf16 [B, H * 128]).  workspace >= arcq_harness_attn_workspace_bytes(B, H, Tmax).
+extern "C" int arcq_harness_attn_decode_window(const void* qkv, void* kcache, void* vcache, void* out, void* workspace, int64_t B, int64_t H,
+                                               int64_t Tmax, int64_t pos, int64_t first, void* stream);
 extern "C" int arcq_harness_attn_decode(const void* qkv, void* kcache, void* vcache, void* out, void* workspace, int64_t B, int64_t H, int64_t Tmax,
                                         int64_t pos, void* stream) {
+  return arcq_harness_attn_decode_window(qkv, kcache, vcache, out, workspace, B, H, Tmax, pos, 0, stream);
+}
+
+// the same over positions [first, pos] only (first == pos: what benchmarks/modeling_arc.py:169-198 attends over in a decode step)
+extern "C" int arcq_harness_attn_decode_window(const void* qkv, void* kcache, void* vcache, void* out, void* workspace, int64_t B, int64_t H,
+                                               int64_t Tmax, int64_t pos, int64_t first, void* stream) {
   const char* who = "arcq_harness_attn_decode";
-  if (B <= 0 || H <= 0 || Tmax <= 0 || pos < 0 || pos >= Tmax) return fail(ARCQ_ERR_SHAPE, "%s: bad B / H / Tmax / pos", who);
+  if (B <= 0 || H <= 0 || Tmax <= 0 || pos < 0 || pos >= Tmax || first < 0 || first > pos) return fail(ARCQ_ERR_SHAPE, "%s: bad B / H / Tmax / pos / first", who);
   if (!qkv || !kcache || !vcache || !out || !workspace) return fail(ARCQ_ERR_NULL, "%s: NULL pointer", who);
   if ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(kcache) | reinterpret_cast<uintptr_t>(vcache)) & 15)
     return fail(ARCQ_ERR_SHAPE, "%s: qkv and the caches must be 16-byte aligned", who);
   AttnParams p;
   p.qkv = (const uint16_t*)qkv; p.kcache = (uint16_t*)kcache; p.vcache = (uint16_t*)vcache; p.ws = (float*)workspace; p.out = (uint16_t*)out;
-  p.B = (int)B; p.H = (int)H; p.Tmax = (int)Tmax; p.pos = (int)pos;
+  p.B = (int)B; p.H = (int)H; p.Tmax = (int)Tmax; p.pos = (int)pos; p.first = (int)first;
   // slices of >= 128 positions, enough of them to give every CU a workgroup, at most kAttnMaxChunk positions each; the slice
   // count is fixed per Tmax (workspace layout), the slices beyond pos stay empty
-  const int T = (int)pos + 1;
+  const int T = (int)(pos + 1 - first);
   int S = (int)((Tmax + 255) / 256);
   int chunk = (T + S - 1) / S;
   chunk = (chunk + 15) & ~15;
@@ -197,7 +209,7 @@ extern "C" int arcq_harness_attn_decode(const void* qkv, void* kcache, void* vca
   p.scale = 0.08838834764831845f;                           // 128^-0.5
   const int live = (T + chunk - 1) / chunk;
   hipLaunchKernelGGL(attn_decode_partial, dim3((unsigned)(B * H), (unsigned)live), dim3(kAttnThreads), 0, (hipStream_t)stream, p);
-  hipLaunchKernelGGL(attn_decode_combine, dim3((unsigned)(B * H)), dim3(kAttnD), 0, (hipStream_t)stream, p);
+  if (live > 1) hipLaunchKernelGGL(attn_decode_combine, dim3((unsigned)(B * H)), dim3(kAttnD), 0, (hipStream_t)stream, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "%s: launch failed: %s", who, hipGetErrorString(e));
   return ARCQ_OK;

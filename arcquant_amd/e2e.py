@@ -162,7 +162,7 @@ class DecoderModel:
             else:
                 A, SFA = agemm.rmsnorm_quantize_x(hcur, L["ln1"], cfg.eps, self.idx_h, ke)
                 q, k, v = (self._ref_linear(L[n], A, SFA, L[n].scale) for n in ("q", "k", "v"))
-            if self.fused and self.attention == "cache" and q_len == 1 and hd == 128 and self.decode_attention == "stream":
+            if self.fused and q_len == 1 and hd == 128 and self.decode_attention == "stream":
                 att = self._attn_decode_stream(qkv, L, pos)          # K|V append + attention over [0, pos]: the harness's own kernel
             else:
                 att = self._attention_torch(L, q, k, v, qkv if self.fused else None, pos, bsz, q_len)
@@ -246,7 +246,8 @@ class DecoderModel:
 
     def _attn_decode_stream(self, qkv, L, pos):
         """One decode step of attention over the dense bf16 cache with the harness kernel (include/arcq_harness.h): appends this
-        token's k / v at `pos` and attends over [0, pos]; fp32 math, bf16 out [batch, hidden]."""
+        token's k / v at `pos` and attends over [0, pos] (attention="cache") or over the current token only ("current", what
+        benchmarks/modeling_arc.py:169-198 times); fp32 math, bf16 out [batch, hidden]."""
         from . import _lib
         lib = _lib.lib()
         bsz, nh = qkv.shape[0], self.cfg.num_heads
@@ -255,8 +256,9 @@ class DecoderModel:
             self._attn_ws = torch.empty(int(lib.arcq_harness_attn_workspace_bytes(bsz, nh, tmax)) // 4, dtype=torch.float32, device=qkv.device)
         out = torch.empty((bsz, self.cfg.hidden_size), dtype=torch.bfloat16, device=qkv.device)
         with torch.cuda.device(qkv.device):
-            st = lib.arcq_harness_attn_decode(qkv.data_ptr(), L["kc"].data_ptr(), L["vc"].data_ptr(), out.data_ptr(), self._attn_ws.data_ptr(),
-                                              bsz, nh, tmax, int(pos), torch.cuda.current_stream(qkv.device).cuda_stream)
+            st = lib.arcq_harness_attn_decode_window(qkv.data_ptr(), L["kc"].data_ptr(), L["vc"].data_ptr(), out.data_ptr(), self._attn_ws.data_ptr(),
+                                                     bsz, nh, tmax, int(pos), 0 if self.attention == "cache" else int(pos),
+                                                     torch.cuda.current_stream(qkv.device).cuda_stream)
         _lib.check(st, "harness attn_decode")
         return out
 

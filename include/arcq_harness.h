@@ -25,6 +25,10 @@ int64_t arcq_harness_attn_workspace_bytes(int64_t B, int64_t H, int64_t Tmax);
  * out[b, h*128 + d] = softmax(q k^T / sqrt(128)) v over positions [0, pos] (fp32 math, bf16 result).  Two launches on `stream`. */
 int arcq_harness_attn_decode(const void *qkv, void *kcache, void *vcache, void *out, void *workspace, int64_t B, int64_t H,
                              int64_t Tmax, int64_t pos, void *stream);
+/* The same over positions [first, pos] only (0 <= first <= pos); first == pos is the attention benchmarks/modeling_arc.py:169-198
+ * times in a decode step (each sequence attends over the tokens of the current call).  One launch when the window is one slice. */
+int arcq_harness_attn_decode_window(const void *qkv, void *kcache, void *vcache, void *out, void *workspace, int64_t B, int64_t H,
+                                    int64_t Tmax, int64_t pos, int64_t first, void *stream);
 
 #ifdef __cplusplus
 }

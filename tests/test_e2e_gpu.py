@@ -169,3 +169,39 @@ def test_harness_decode_attention_kernel_matches_torch_sdpa():
         want = want.transpose(1, 2).reshape(bsz, h)
         err = float((got.float() - want).abs().max())
         assert err <= 2.0 ** -7 * float(want.abs().max()) + 1e-3, (pos, err)
+
+
+def test_harness_decode_attention_window_is_the_current_token():
+    """attention="current" (benchmarks/modeling_arc.py:169-198: a decode step attends over the tokens of the current call, i.e. the
+    one new token): softmax over one key is 1, so the output IS this token's v, bit for bit, in ONE launch; k / v are still
+    appended.  A window in the middle of the cache ([first, pos]) against torch over the same slice."""
+    import torch.nn.functional as F
+    from arcquant_amd import _lib
+    e2e, _ = _toy()
+    cfg = e2e.ModelConfig("toyattn", num_layers=1, num_heads=4, hidden_size=512, intermediate_size=1024, vocab_size=64)
+    dev = torch.device("cuda:0")
+    bsz, tmax, nh, hd, h = 3, 600, 4, 128, 512
+    model = e2e.DecoderModel(cfg, bsz, tmax, dev, fused=True, attention="current")
+    L = model.layers[0]
+    g = torch.Generator(device=dev).manual_seed(4)
+    for pos in (0, 17, 599):
+        L["kv"].copy_(torch.randn(L["kv"].shape, generator=g, device=dev).to(torch.bfloat16))
+        before = L["kv"].clone()
+        qkv = torch.randn(bsz, 3 * h, generator=g, device=dev).to(torch.bfloat16)
+        got = model._attn_decode_stream(qkv, L, pos)
+        assert torch.equal(got, qkv[:, 2 * h:]), pos
+        want_kv = before.clone()
+        want_kv[:, :, :, pos:pos + 1] = qkv[:, h:].reshape(bsz, 1, 2, nh, hd).permute(2, 0, 3, 1, 4)
+        assert torch.equal(L["kv"], want_kv), pos
+    lib = _lib.lib()
+    for first, pos in ((100, 420), (299, 300), (0, 599)):
+        qkv = torch.randn(bsz, 3 * h, generator=g, device=dev).to(torch.bfloat16)
+        out = torch.empty((bsz, h), dtype=torch.bfloat16, device=dev)
+        st = lib.arcq_harness_attn_decode_window(qkv.data_ptr(), L["kc"].data_ptr(), L["vc"].data_ptr(), out.data_ptr(), model._attn_ws.data_ptr(),
+                                                 bsz, nh, tmax, pos, first, torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(st, "window")
+        q = qkv[:, :h].reshape(bsz, 1, nh, hd).transpose(1, 2)
+        want = F.scaled_dot_product_attention(q.float(), L["kc"][:, :, first:pos + 1].float(), L["vc"][:, :, first:pos + 1].float())
+        want = want.transpose(1, 2).reshape(bsz, h)
+        err = float((out.float() - want).abs().max())
+        assert err <= 2.0 ** -7 * float(want.abs().max()) + 1e-3, (first, pos, err)
