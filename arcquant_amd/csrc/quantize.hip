@@ -104,6 +104,7 @@ __device__ __forceinline__ float rms_sumsq_tree(float* s, int bdx, float p_lo, f
 // kDyn / kSilu are template parameters: as run-time branches inside the 16-element gather they cost the static
 // quantiser 18 % (15.7 -> 18.5 us at 4096^2) and the dynamic one most of its time.
 enum : int { kDynNone = 0, kDynState = 1, kDynLocal = 2 };
+constexpr int kGatherCache = 2;   // groups per thread whose gather offsets live in registers across rows
 
 template <int kVariant, int kMode, int kDyn, int kSilu>
 __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
@@ -157,6 +158,24 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
       lds_store_chunk(wn_lds, c, *reinterpret_cast<const uint4*>(Wn + (size_t)c * 8));
     // visible after the barriers of the first row's reduction
   }
+  // Every row of this workgroup gathers through the same reorder_index: the LDS byte offsets of a thread's first kGatherCache
+  // groups (all of them up to KQ = 8192) are computed ONCE -- per row that leaves one ds_read_u16 + one shift per element instead
+  // of two index loads and ~5 integer instructions per element (the kernel is issue-bound).
+  const bool cache_on = !(kSilu && gridDim.y > 1);           // that path gathers from global memory by element index
+  uint32_t gofs[kGatherCache][16];
+#pragma unroll
+  for (int c = 0; c < kGatherCache; ++c) {
+    const int g = min(g_begin + tid + c * kQuantThreads, G - 1);
+    const uint4 i0 = *reinterpret_cast<const uint4*>(idx + (size_t)g * 16);
+    const uint4 i1 = *reinterpret_cast<const uint4*>(idx + (size_t)g * 16 + 8);
+    const uint32_t iw[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t pw = lds_pad_pair(iw[j]);
+      gofs[c][2 * j] = (pw & 0xffffu) * 2;
+      gofs[c][2 * j + 1] = (pw >> 16) * 2;
+    }
+  }
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     const uint16_t* xrow = X + (size_t)row * ldx;
     float rstd = 1.0f;
@@ -202,36 +221,9 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
     }
 
     uint8_t* qrow = Q + (size_t)row * (K >> 1);
-    for (int g = g_begin + tid; g < g_end; g += kQuantThreads) {
-      // reorder_index for this group: 16 x int16 = two 16-byte loads
-      const uint4 i0 = *reinterpret_cast<const uint4*>(idx + (size_t)g * 16);
-      const uint4 i1 = *reinterpret_cast<const uint4*>(idx + (size_t)g * 16 + 8);
-      const uint32_t iw[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
-      float v[16];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const uint32_t ia = iw[j] & 0xffffu, ib = iw[j] >> 16;
-        const uint32_t pw = lds_pad_pair(iw[j]), pa = pw & 0xffffu, pb = pw >> 16;      // the same elements in the padded LDS rows
-        float a, b;
-        if (kSilu && gridDim.y > 1) {
-          const uint16_t* urow = Xup + (size_t)row * ldx;
-          a = bf16_bits_to_f32(silu_act_elem<kSilu>(xrow, urow, ia));
-          b = bf16_bits_to_f32(silu_act_elem<kSilu>(xrow, urow, ib));
-        } else {
-          a = bf16_bits_to_f32(row_lds[pa]);
-          b = bf16_bits_to_f32(row_lds[pb]);
-        }
-        if (kDyn != kDynNone) {                                 // torch: bf16(float(x) / scale)
-          a = round_to_bf16(div_scale(a));
-          b = round_to_bf16(div_scale(b));
-        }
-        if (kMode == kModeRms) {                                // rmsnorm.cu:165-171
-          a = round_to_bf16(a * bf16_bits_to_f32(wn_lds[pa]) * rstd);
-          b = round_to_bf16(b * bf16_bits_to_f32(wn_lds[pb]) * rstd);
-        }
-        v[2 * j] = a;
-        v[2 * j + 1] = b;
-      }
+    const uint16_t* urow_g = kSilu ? Xup + (size_t)row * ldx : nullptr;
+    // one group: 16 gathered values -> codes + scale byte(s) at the group's augmented-K position
+    auto finish = [&](int g, float (&v)[16]) __attribute__((always_inline)) {
       const bool tail = g >= P;
       // augmented-K position of this group (reorder.cu:139 / :451-452)
       int p;
@@ -269,6 +261,59 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
         *reinterpret_cast<uint2*>(qrow + (size_t)pr * 8) = r.packed;
         SF[sf_offset(row, pr, K)] = (uint8_t)r.s8;
       }
+    };
+    auto scale_pair = [&](float& a, float& b, uint32_t off_a, uint32_t off_b) __attribute__((always_inline)) {
+      if (kDyn != kDynNone) {                                   // torch: bf16(float(x) / scale)
+        a = round_to_bf16(div_scale(a));
+        b = round_to_bf16(div_scale(b));
+      }
+      if (kMode == kModeRms) {                                  // rmsnorm.cu:165-171
+        a = round_to_bf16(a * bf16_bits_to_f32(*reinterpret_cast<const uint16_t*>(reinterpret_cast<const unsigned char*>(wn_lds) + off_a)) * rstd);
+        b = round_to_bf16(b * bf16_bits_to_f32(*reinterpret_cast<const uint16_t*>(reinterpret_cast<const unsigned char*>(wn_lds) + off_b)) * rstd);
+      }
+    };
+    // (a) the thread's first kGatherCache groups: LDS byte offsets computed once per workgroup (gofs)
+#pragma unroll
+    for (int c = 0; c < kGatherCache; ++c) {
+      const int g = g_begin + tid + c * kQuantThreads;
+      if (cache_on && g < g_end) {
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint32_t oa = gofs[c][2 * j], ob = gofs[c][2 * j + 1];
+          float a = bf16_bits_to_f32(*reinterpret_cast<const uint16_t*>(reinterpret_cast<const unsigned char*>(row_lds) + oa));
+          float b = bf16_bits_to_f32(*reinterpret_cast<const uint16_t*>(reinterpret_cast<const unsigned char*>(row_lds) + ob));
+          scale_pair(a, b, oa, ob);
+          v[2 * j] = a;
+          v[2 * j + 1] = b;
+        }
+        finish(g, v);
+      }
+    }
+    // (b) further groups of long rows, and the decode-sized SiLU*up path that gathers straight from global memory
+    for (int g = g_begin + tid + (cache_on ? kGatherCache * kQuantThreads : 0); g < g_end; g += kQuantThreads) {
+      // reorder_index for this group: 16 x int16 = two 16-byte loads
+      const uint4 i0 = *reinterpret_cast<const uint4*>(idx + (size_t)g * 16);
+      const uint4 i1 = *reinterpret_cast<const uint4*>(idx + (size_t)g * 16 + 8);
+      const uint32_t iw[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t ia = iw[j] & 0xffffu, ib = iw[j] >> 16;
+        const uint32_t pw = lds_pad_pair(iw[j]), pa = pw & 0xffffu, pb = pw >> 16;      // the same elements in the padded LDS rows
+        float a, b;
+        if (kSilu && gridDim.y > 1) {
+          a = bf16_bits_to_f32(silu_act_elem<kSilu>(xrow, urow_g, ia));
+          b = bf16_bits_to_f32(silu_act_elem<kSilu>(xrow, urow_g, ib));
+        } else {
+          a = bf16_bits_to_f32(row_lds[pa]);
+          b = bf16_bits_to_f32(row_lds[pb]);
+        }
+        scale_pair(a, b, pa * 2, pb * 2);
+        v[2 * j] = a;
+        v[2 * j + 1] = b;
+      }
+      finish(g, v);
     }
     __syncthreads();   // row_lds is rewritten by the next row
   }
