@@ -28,6 +28,7 @@
 //                    block: the down projection's kSrcDyn prologue then needs no abs-max pass and no SiLU
 //
 // Roofline: HBM.  Bytes per launch = N*K*9/16 (+ padding of K to 256) + activations + output.
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -391,12 +392,18 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
     ARCQ_STAMP(9);
     // ---- (c) quantise group by group straight into the image; the K padding is zero
     const uint16_t* wn_lds = reinterpret_cast<const uint16_t*>(xstage + (size_t)p.M * p.xrow_bytes);
+    // `p.stage` and the divider's fast path are uniform over the launch: the group loop is instantiated per combination (as
+    // branches inside the 16-element gather they cost a scalar branch and a FULL wait per element -- sixteen serialised LDS
+    // round trips per group)
+    const st_u32x4 pi0 = {pre_i0.x, pre_i0.y, pre_i0.z, pre_i0.w}, pi1 = {pre_i1.x, pre_i1.y, pre_i1.z, pre_i1.w};
+    auto run_groups = [&](auto stage_tag, auto fast_tag) __attribute__((always_inline)) {
+    constexpr bool kStage = decltype(stage_tag)::value, kFast = decltype(fast_tag)::value;
     for (int t = tid; t < p.M * G; t += kStThreads) {
       const int m = t / G, g = t - m * G;
-      uint4 i0 = pre_i0, i1 = pre_i1;
+      st_u32x4 i0 = pi0, i1 = pi1;                           // (native vectors: a HIP uint4 captured by the lambda lands in scratch)
       if (t != tid) {                                        // later groups of this thread (M * KQ > 16 K elements)
-        i0 = *reinterpret_cast<const uint4*>(p.idx + (size_t)g * 16);
-        i1 = *reinterpret_cast<const uint4*>(p.idx + (size_t)g * 16 + 8);
+        i0 = *reinterpret_cast<const st_u32x4*>(p.idx + (size_t)g * 16);
+        i1 = *reinterpret_cast<const st_u32x4*>(p.idx + (size_t)g * 16 + 8);
       }
       const uint32_t iw[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
       const uint16_t* xrow_lds = reinterpret_cast<const uint16_t*>(xstage + (size_t)m * p.xrow_bytes);
@@ -405,10 +412,11 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
       float v[16];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
+        if (j == 4) __builtin_amdgcn_sched_barrier(0);         // two batches of LDS reads: 8 address + 8 value registers less
         const uint32_t ia = iw[j] & 0xffffu, ib = iw[j] >> 16;
         const uint32_t pw = lds_pad_pair(iw[j]), pa = pw & 0xffffu, pb = pw >> 16;
         float a, b;
-        if (p.stage) {
+        if (kStage) {
           a = bf16_bits_to_f32(xrow_lds[pa]);
           b = bf16_bits_to_f32(xrow_lds[pb]);
         } else {
@@ -416,8 +424,8 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
           b = bf16_bits_to_f32(xrow_g[ib]);
         }
         if (kSrc == kSrcDyn) {                                 // torch: bf16(float(x) / scale)
-          a = round_to_bf16(dyn_div(a));
-          b = round_to_bf16(dyn_div(b));
+          a = round_to_bf16(dyn_div.template div<kFast>(a));
+          b = round_to_bf16(dyn_div.template div<kFast>(b));
         }
         if (kSrc == kSrcRms) {                                 // rmsnorm.cu:165-171
           a = round_to_bf16(a * bf16_bits_to_f32(wn_lds[pa]) * rstd);
@@ -439,6 +447,16 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
         image_put_group(a_img, p, m, pos, quantize_group<true, kVariant>(v));
         image_put_group(a_img, p, m, pos + (kVariant == ARCQ_VARIANT_G16 ? 1 : 2), quantize_group<false, kVariant>(v));
       }
+    }
+    };
+    if constexpr (kSrc == kSrcRms) {
+      run_groups(std::true_type{}, std::true_type{});          // always staged (stream_geometry), no division
+    } else if (p.stage) {
+      if (dyn_div.fast) run_groups(std::true_type{}, std::true_type{});
+      else run_groups(std::true_type{}, std::false_type{});
+    } else {
+      if (dyn_div.fast) run_groups(std::false_type{}, std::true_type{});
+      else run_groups(std::false_type{}, std::false_type{});
     }
     const int pad_groups = P * 16 - (p.K >> 4);               // zero scale bytes of the repacked weight meet zeros here
     for (int t = tid; t < p.M * pad_groups; t += kStThreads) {

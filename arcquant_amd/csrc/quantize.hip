@@ -16,6 +16,7 @@
 //
 // Numerics follow the kernel text of the reference exactly (see oracle/arcq_oracle.c for the CPU
 // restatement these kernels are tested against, byte for byte).
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -149,7 +150,6 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
     dyn_scale = round_to_bf16(dyn_scale);
   }
   const DynDiv dyn_div(dyn_scale, kDyn != kDynNone);       // x / scale, bit-exact (quantize_device.hpp)
-  auto div_scale = [&](float x) -> float { return dyn_div(x); };
 
   if (kMode == kModeRms) {
     // the gather reads the norm weight of every channel: 16 scattered 2-byte global loads per group cost 2.6x
@@ -176,6 +176,8 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
       gofs[c][2 * j + 1] = (pw >> 16) * 2;
     }
   }
+  auto run_rows = [&](auto fast_tag) __attribute__((always_inline)) {
+  constexpr bool kFast = decltype(fast_tag)::value;
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     const uint16_t* xrow = X + (size_t)row * ldx;
     float rstd = 1.0f;
@@ -264,8 +266,8 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
     };
     auto scale_pair = [&](float& a, float& b, uint32_t off_a, uint32_t off_b) __attribute__((always_inline)) {
       if (kDyn != kDynNone) {                                   // torch: bf16(float(x) / scale)
-        a = round_to_bf16(div_scale(a));
-        b = round_to_bf16(div_scale(b));
+        a = round_to_bf16(dyn_div.template div<kFast>(a));
+        b = round_to_bf16(dyn_div.template div<kFast>(b));
       }
       if (kMode == kModeRms) {                                  // rmsnorm.cu:165-171
         a = round_to_bf16(a * bf16_bits_to_f32(*reinterpret_cast<const uint16_t*>(reinterpret_cast<const unsigned char*>(wn_lds) + off_a)) * rstd);
@@ -317,6 +319,13 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
     }
     __syncthreads();   // row_lds is rewritten by the next row
   }
+  };
+  if constexpr (kDyn == kDynNone) {
+    run_rows(std::true_type{});
+  } else {
+    if (dyn_div.fast) run_rows(std::true_type{});
+    else run_rows(std::false_type{});
+  }
 }
 
 // The dynamic-scale activation quantiser for an input that is ALREADY in reordered channel order (reorder_index == NULL at the
@@ -344,6 +353,8 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_contig_dyn_kernel(cons
   dyn_scale = round_to_bf16(dyn_scale);                   // torch divides by the scale rounded to bf16 (see quantize_rows_kernel)
   const DynDiv dyn_div(dyn_scale, true);
   const int64_t total = (int64_t)rows * G;
+  auto run = [&](auto fast_tag) __attribute__((always_inline)) {
+  constexpr bool kFast = decltype(fast_tag)::value;
   for (int64_t t = (int64_t)blockIdx.x * kQuantThreads + tid; t < ((total + 3) & ~(int64_t)3); t += (int64_t)gridDim.x * kQuantThreads) {
     const bool live = t < total;                          // (total is a multiple of 4: whole quads are live or dead together)
     const int64_t tc = live ? t : total - 1;
@@ -354,8 +365,8 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_contig_dyn_kernel(cons
     float v[16];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      v[2 * j] = round_to_bf16(dyn_div(bf16_bits_to_f32(w[j] & 0xffffu)));
-      v[2 * j + 1] = round_to_bf16(dyn_div(bf16_bits_to_f32(w[j] >> 16)));
+      v[2 * j] = round_to_bf16(dyn_div.template div<kFast>(bf16_bits_to_f32(w[j] & 0xffffu)));
+      v[2 * j + 1] = round_to_bf16(dyn_div.template div<kFast>(bf16_bits_to_f32(w[j] >> 16)));
     }
     const bool tail = g >= P;
     int p;
@@ -384,6 +395,9 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_contig_dyn_kernel(cons
       SF[sf_offset(row, pr, K)] = (uint8_t)r.s8;
     }
   }
+  };
+  if (dyn_div.fast) run(std::true_type{});
+  else run(std::false_type{});
 }
 
 // max|x| helpers.  |bf16| ordering == ordering of the low 15 bits, so integer max is exact.

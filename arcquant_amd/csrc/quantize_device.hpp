@@ -101,14 +101,18 @@ struct DynDiv {
   float scale, rcp;
   bool fast;
   __device__ __forceinline__ DynDiv(float s, bool enabled) : scale(s), rcp(1.0f / s), fast(enabled && s >= 0x1p-100f && s <= 0x1p100f) {}
-  __device__ __forceinline__ float operator()(float x) const {
-    if (__builtin_expect(fast, 1)) {
+  // `fast` is uniform over the launch: callers test it ONCE and instantiate their element loops for either value (as a branch per
+  // element it costs a scalar branch and a full wait on outstanding loads for each of the 16 values of a group)
+  template <bool kFast>
+  __device__ __forceinline__ float div(float x) const {
+    if constexpr (kFast) {
       float q = x * rcp;
       const float e = __builtin_fmaf(-q, scale, x);
       q = __builtin_fmaf(e, rcp, q);
       return __builtin_copysignf(q, x);
+    } else {
+      return x / scale;
     }
-    return x / scale;
   }
 };
 

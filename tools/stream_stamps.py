@@ -34,7 +34,7 @@ def run(m, n, kq, mode):
     wn = torch.ones(kq, dtype=torch.bfloat16, device=dev)
     for i in range(rot):
         if mode == "packed":
-            agemm.matmul_repacked(q["qx"], rps[i][0], q["sfx"], rps[i][1], q["alpha"], n, out=o)
+            agemm.matmul_repacked(q["qx"], rps[i][0], q["sfx"], rps[i][1], q["alpha"], n, out=o, kernel="stream")
         elif mode == "rms":
             agemm.rmsnorm_matmul_repacked(q["x"], wn, 1e-6, q["idx"], KE, rps[i][0], rps[i][1], 1.0, n, out=o)
         else:
@@ -61,5 +61,5 @@ def run(m, n, kq, mode):
 
 if __name__ == "__main__":
     for (m, n, kq) in [(1, 4096, 4096), (4, 3584, 3584), (4, 10752, 3584), (4, 37888, 3584), (4, 3584, 18944)]:
-        for mode in ("packed",) + (("rms",) if kq <= 8192 else ()):
+        for mode in ("packed", "dyn") + (("rms",) if kq <= 8192 else ()):
             run(m, n, kq, mode)
