@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Regenerate the two measured tables of DESIGN.md (between the <!-- decode-table --> / <!-- results --> markers) from
+profiles/r02_bench_full.json and profiles/r02_bench_profiled_stdout.json, so the document quotes the committed run."""
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_full.json")))
+prof = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_profiled_stdout.json")))
+trace = open(os.path.join(ROOT, "profiles", "r02_bench_kernel_trace_summary.txt")).read()
+e = d["extra"]
+names = {"decode_gemm_M1_N4096_KQ4096": "config[1] M=1 N=4096 KQ=4096", "decode_gemm_M4_N4096_KQ4096": "M=4 N=4096 KQ=4096",
+         "decode_gemm_M16_N4096_KQ4096": "M=16 N=4096 KQ=4096", "decode_gemm_M1_N14336_KQ4096": "config[2] gate/up M=1 N=14336 KQ=4096",
+         "decode_gemm_M1_N4096_KQ14336": "config[2] down M=1 N=4096 KQ=14336", "decode_gemm_M1_N1024_KQ4096": "config[2] k/v M=1 N=1024 KQ=4096",
+         "decode_gemm_M4_N3584_KQ3584": "config[3] o M=4 N=3584 KQ=3584", "decode_gemm_M4_N10752_KQ3584": "config[3] q|k|v M=4 N=10752 KQ=3584",
+         "decode_gemm_M4_N37888_KQ3584": "config[3] gate|up M=4 N=37888 KQ=3584", "decode_gemm_M4_N3584_KQ18944": "config[3] down M=4 N=3584 KQ=18944"}
+t = "| shape (KE = 64) | reference layout µs | repacked µs | TB/s (best) | of 8 TB/s | fp16 library µs | speed-up |\n|---|---|---|---|---|---|---|\n"
+for k, n in names.items():
+    v = e[k]
+    t += (f"| {n} | {v['reference_layout_us']:.2f} | {v['repacked_us']:.2f} | {v['GBps'] / 1000:.2f} | {v['frac_hbm_peak']:.2f} | "
+          f"{v['fp16_rocblas_us']:.1f} | {v['speedup_vs_fp16_rocblas']:.2f}× |\n")
+l = e["llama3_8b_layer_linears_decode"]
+t += f"| Llama-3-8B layer, 7 linears, M=1 | | {l['us']:.1f} | {l['GBps'] / 1000:.2f} | {l['GBps'] / 8000:.2f} | {l['fp16_rocblas_us']:.1f} | {l['speedup_vs_fp16_rocblas']:.2f}× |\n"
+p = e["qwen2.5-7b_e2e_reference_protocol"]
+hg, ea = p["hip_graph"], p["eager"]
+m = re.search(r"last 200 \(the timed steps\) average ([0-9.]+) us", trace)
+cpu_s = d["cpu_baseline"]["sample"].split("best of 2 = ")[1].split(" ")[0]
+res = f"""**Results of the committed run** (`profiles/r02_bench_full.json`, one MI355X; the same command under `rocprofv3 --kernel-trace --stats`:
+`profiles/r02_bench_kernel_trace_summary.txt`, `r02_bench_kernel_stats.csv`). Box to box the sustained headline ranged 1346–1391 TFLOP/s this
+round (`roofline.frac` 0.54–0.56), the library GEMM beside it 1395–1457:
+
+| what | value |
+|---|---|
+| headline: ARC-NVFP4 GEMM M=N=KQ=4096, KE=64 | **{d['value']:.0f} TFLOP/s**, {d['roofline']['kernel_us']:.1f} µs per launch, `roofline.frac` **{d['roofline']['frac']:.3f}** of the 2.5 PFLOP/s fp16 roof ({d['roofline']['frac_of_fp4_peak']:.3f} of the fp4 roof) |
+| same launch under rocprofv3 | the 200 timed dispatches average {m.group(1)} µs in the kernel trace against {prof['roofline']['kernel_us']:.2f} µs from that run's own events |
+| fp16 library GEMM, same shape, same state | {e['gemm_4096']['fp16_rocblas_TFLOPs']:.0f} TFLOP/s (ours {e['gemm_4096']['speedup_vs_fp16_rocblas']:.3f}×); 8192²: ours {e['gemm_8192']['TFLOPs']:.0f} vs {e['gemm_8192']['fp16_rocblas_TFLOPs']:.0f} ({e['gemm_8192']['speedup_vs_fp16_rocblas']:.3f}×) |
+| `cpu_baseline` (port of the reference's fake path, {d['cpu_baseline']['cores']} host threads, full workload) | {d['cpu_baseline']['value'] * 1000:.1f} GFLOP/s-equivalent ({cpu_s} s per step) |
+| quantiser, static, graph replay | 4096²: {e['quantize_x_4096']['us']:.1f} µs = {e['quantize_x_4096']['GBps'] / 1000:.2f} TB/s; 8192²: {e['quantize_x_8192']['us']:.1f} µs = {e['quantize_x_8192']['GBps'] / 1000:.2f} TB/s |
+| Qwen2.5-7B shape, bs = 4, reference protocol (prefill 1024 + 128 decode steps over the growing cache, biases on) | HIP graph: prefill {hg['prefill_ms'][0]:.1f} ms ({hg['prefill_tok_per_s']:.0f} tok/s), decode {hg['decode_ms'][0]:.1f} ± {hg['decode_ms'][1]:.1f} ms = **{hg['decode_tok_per_s']:.0f} tok/s**, e2e {hg['e2e_ms'][0]:.1f} ms, peak {hg['peak_memory_gb']:.1f} GB; eager launches: decode {ea['decode_ms'][0]:.1f} ms = {ea['decode_tok_per_s']:.0f} tok/s |
+| one decode step at 1040 cached tokens | full-cache attention {e['qwen2.5-7b_decode_step_full_cache']['decode_tok_per_s']:.0f} tok/s (round 1: 1001–1079; with torch SDPA instead of the harness kernel {e['qwen2.5-7b_decode_step_full_cache_torch_sdpa_attention']['decode_tok_per_s']:.0f}); current-token attention (the reference harness's quirk) {e['qwen2.5-7b_decode_step_current_token_attention_harness_quirk']['decode_tok_per_s']:.0f} (round 1: 1711 without biases); the reference's unfused call structure on the same kernels {e['qwen2.5-7b_decode_step_reference_call_structure']['decode_tok_per_s']:.0f} |
+"""
+path = os.path.join(ROOT, "DESIGN.md")
+s = open(path).read()
+s = re.sub(r"<!-- decode-table -->.*?<!-- /decode-table -->", "<!-- decode-table -->\n" + t + "<!-- /decode-table -->", s, flags=re.S)
+s = re.sub(r"<!-- results -->.*?<!-- /results -->", "<!-- results -->\n" + res + "<!-- /results -->", s, flags=re.S)
+open(path, "w").write(s)
+print("DESIGN.md tables regenerated")
