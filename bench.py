@@ -144,7 +144,10 @@ def bench_extra(args, device, rank):
     #      ">= 3.5x fp16 rocBLAS" is physically reachable.
     KE = 64
     for (m, n, kq) in [(1, 4096, 4096), (4, 4096, 4096), (16, 4096, 4096), (1, 14336, 4096), (1, 4096, 14336), (1, 1024, 4096),
-                       (4, 3584, 3584), (4, 10752, 3584), (4, 37888, 3584), (4, 3584, 18944)]:
+                       (4, 3584, 3584), (4, 10752, 3584), (4, 37888, 3584), (4, 3584, 18944),
+                       # config[4], one rank of Llama-3-70B TP=8 at bs=4: q|k|v and gate|up column shards (N = 10240/8, 57344/8),
+                       # o / down row shards (the largest K slice of tp.k_slices: 1088 and 3648 of K_aug = 8256 / 28736)
+                       (4, 1280, 8192), (4, 7168, 8192), (4, 8192, 1024), (4, 8192, 3584)]:
         q = make_problem(m, n, kq, KE, device)
         K = kq + KE
         rot = max(2, int(320e6 // (n * K * 9 / 16)) + 1)
@@ -218,6 +221,20 @@ def bench_extra(args, device, rank):
         extra["llama3_8b_layer_linears_decode"] = {"us": round(c3, 2), "GBps": round(wbytes / c3 / 1e3, 1), "fp16_rocblas_us": round(c3_16, 2),
                                                   "speedup_vs_fp16_rocblas": round(c3_16 / c3, 2),
                                                   "note": "q,o 4096x4096; k,v 1024x4096; gate,up 14336x4096; down 4096x14336; M=1, KE=64"}
+    except KeyError:
+        pass
+    # ---- BASELINE config[4]: the four sharded linears of one Llama-3-70B layer on ONE of 8 ranks (bs=4 decode); the two all-reduces
+    #      (4 x 8192 fp32 partials = 128 KB each) and the hand-off (tp.handoff_*) are the driver's multi-GPU run to measure
+    try:
+        keys = ["decode_gemm_M4_N1280_KQ8192", "decode_gemm_M4_N7168_KQ8192", "decode_gemm_M4_N8192_KQ1024", "decode_gemm_M4_N8192_KQ3584"]
+        c4 = sum(extra[k]["us_per_launch_graph"] for k in keys)
+        c4_16 = sum(extra[k]["fp16_rocblas_us"] for k in keys)
+        wb4 = (1280 + 7168) * 8256 * 9 / 16 + 8192 * (1088 + 3648) * 9 / 16
+        extra["llama3_70b_tp8_rank_linears_decode"] = {"us": round(c4, 2), "GBps": round(wb4 / c4 / 1e3, 1), "fp16_rocblas_us": round(c4_16, 2),
+                                                      "speedup_vs_fp16_rocblas": round(c4_16 / c4, 2),
+                                                      "note": "per rank of TP=8, M=4, KE=64: q|k|v 1280x8192 and gate|up 7168x8192 column shards, "
+                                                              "o 8192x1088 and down 8192x3648 row shards (K slices of the augmented axis); "
+                                                              "collectives not included (single GPU)"}
     except KeyError:
         pass
     # ---- decode-batch / short-prefill token counts (split-K tiles) and the decode-step quantisers, graph-timed

@@ -14,14 +14,21 @@ names = {"decode_gemm_M1_N4096_KQ4096": "config[1] M=1 N=4096 KQ=4096", "decode_
          "decode_gemm_M16_N4096_KQ4096": "M=16 N=4096 KQ=4096", "decode_gemm_M1_N14336_KQ4096": "config[2] gate/up M=1 N=14336 KQ=4096",
          "decode_gemm_M1_N4096_KQ14336": "config[2] down M=1 N=4096 KQ=14336", "decode_gemm_M1_N1024_KQ4096": "config[2] k/v M=1 N=1024 KQ=4096",
          "decode_gemm_M4_N3584_KQ3584": "config[3] o M=4 N=3584 KQ=3584", "decode_gemm_M4_N10752_KQ3584": "config[3] q|k|v M=4 N=10752 KQ=3584",
-         "decode_gemm_M4_N37888_KQ3584": "config[3] gate|up M=4 N=37888 KQ=3584", "decode_gemm_M4_N3584_KQ18944": "config[3] down M=4 N=3584 KQ=18944"}
+         "decode_gemm_M4_N37888_KQ3584": "config[3] gate|up M=4 N=37888 KQ=3584", "decode_gemm_M4_N3584_KQ18944": "config[3] down M=4 N=3584 KQ=18944",
+         "decode_gemm_M4_N1280_KQ8192": "config[4] rank q|k|v M=4 N=1280 KQ=8192", "decode_gemm_M4_N7168_KQ8192": "config[4] rank gate|up M=4 N=7168 KQ=8192",
+         "decode_gemm_M4_N8192_KQ1024": "config[4] rank o M=4 N=8192 K slice 1088", "decode_gemm_M4_N8192_KQ3584": "config[4] rank down M=4 N=8192 K slice 3648"}
 t = "| shape (KE = 64) | reference layout µs | repacked µs | TB/s (best) | of 8 TB/s | fp16 library µs | speed-up |\n|---|---|---|---|---|---|---|\n"
 for k, n in names.items():
+    if k not in e:
+        continue
     v = e[k]
     t += (f"| {n} | {v['reference_layout_us']:.2f} | {v['repacked_us']:.2f} | {v['GBps'] / 1000:.2f} | {v['frac_hbm_peak']:.2f} | "
           f"{v['fp16_rocblas_us']:.1f} | {v['speedup_vs_fp16_rocblas']:.2f}× |\n")
 l = e["llama3_8b_layer_linears_decode"]
 t += f"| Llama-3-8B layer, 7 linears, M=1 | | {l['us']:.1f} | {l['GBps'] / 1000:.2f} | {l['GBps'] / 8000:.2f} | {l['fp16_rocblas_us']:.1f} | {l['speedup_vs_fp16_rocblas']:.2f}× |\n"
+if "llama3_70b_tp8_rank_linears_decode" in e:
+    l = e["llama3_70b_tp8_rank_linears_decode"]
+    t += f"| Llama-3-70B layer on one of 8 ranks, 4 sharded linears, M=4 | | {l['us']:.1f} | {l['GBps'] / 1000:.2f} | {l['GBps'] / 8000:.2f} | {l['fp16_rocblas_us']:.1f} | {l['speedup_vs_fp16_rocblas']:.2f}× |\n"
 p = e["qwen2.5-7b_e2e_reference_protocol"]
 hg, ea = p["hip_graph"], p["eager"]
 m = re.search(r"last 200 \(the timed steps\) average ([0-9.]+) us", trace)

@@ -27,7 +27,7 @@ __global__ void k_read(const uint4* __restrict__ src, size_t n16, unsigned* __re
 }
 
 int main() {
-  const size_t sizes[] = {9584640, 33546240, 134184960};
+  const size_t sizes[] = {9584640, 22063104, 40108032, 83066880, 134184960};
   for (size_t bytes : sizes) {
     int rot = (int)(340000000 / bytes) + 1; if (rot < 2) rot = 2;
     std::vector<uint4*> bufs(rot);
