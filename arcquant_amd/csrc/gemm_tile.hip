@@ -72,85 +72,71 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
 
   // ---- XCD-aware tile order: blocks that land on one XCD (id % 8) get a contiguous range of tiles, and
   //      within it tiles walk M fastest in groups of 8 so concurrently resident blocks share B panels.
-  //      PERSISTENT form: the grid may be smaller than the number of (tile, split) blocks; workgroup b then walks the virtual
-  //      block ids b, b + gridDim.x, ... (gridDim.x is a multiple of 8 then, so a workgroup stays on its XCD's range), and the
-  //      first operand loads of its NEXT tile are issued before the epilogue of this one: the output burst drains under the
-  //      next K loop instead of at the end of a one-tile workgroup's life.
   const int ntiles = p.tiles_m * p.tiles_n;
-  const int nblocks = ntiles * p.splits;
+  int bid = blockIdx.x, split = 0;
+  if (p.splits > 1) {
+    split = bid / ntiles;
+    bid -= split * ntiles;
+  }
+  {
+    const int q8 = ntiles >> 3, r8 = ntiles & 7, x = bid & 7, j = bid >> 3;
+    bid = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + j;     // bijective for any ntiles
+  }
+  constexpr int kGroupM = 8;
+  const int per_group = kGroupM * p.tiles_n;
+  const int grp = bid / per_group;
+  const int first_m = grp * kGroupM;
+  const int gsz = min(p.tiles_m - first_m, kGroupM);
+  const int tm = first_m + (bid % per_group) % gsz;
+  const int tn = (bid % per_group) / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WAVES_N, wc = wave % WAVES_N;
   const int half_k = p.K >> 1, atoms_k = p.K >> 6;
-  int split = 0, m0 = 0, n0 = 0, a_begin = 0, a_end = 0;
+  const int a_begin = split * p.atoms_per_split, a_end = min(atoms_k, a_begin + p.atoms_per_split);   // never empty
 
-  // ---- per-thread staging geometry (invariant over a tile's K loop)
+  // ---- per-thread staging geometry (loop invariant)
   const uint8_t* a_q[A_UNITS];
   const uint8_t* a_sf[A_UNITS];
   uint32_t a_live[A_UNITS];
   int a_slot[A_UNITS][4];
+#pragma unroll
+  for (int u = 0; u < A_UNITS; ++u) {
+    const int unit = tid + u * kThreads, r = A_PARTIAL ? min(unit >> 1, BM - 1) : unit >> 1, h = unit & 1;
+    const int row = m0 + r, rc = row < p.M ? row : p.M - 1;
+    a_q[u] = p.A + (size_t)rc * half_k + h * 16;
+    a_sf[u] = p.SFA + sf_atom_offset(rc, 0, atoms_k) + h * 2;
+    a_live[u] = row < p.M ? 0xffffu : 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a_slot[u][j] = kMfma32 ? lds_slot32(r, h * 4 + j) : lds_slot(r, h * 4 + j);
+  }
   const uint8_t* b_q[B_UNITS];
   const uint8_t* b_sf[B_UNITS];
   uint32_t b_live[B_UNITS];
   int b_slot[B_UNITS][4];
 #pragma unroll
-  for (int u = 0; u < A_UNITS; ++u) {
-    const int unit = tid + u * kThreads, r = A_PARTIAL ? min(unit >> 1, BM - 1) : unit >> 1, h = unit & 1;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) a_slot[u][j] = kMfma32 ? lds_slot32(r, h * 4 + j) : lds_slot(r, h * 4 + j);
-  }
-#pragma unroll
   for (int u = 0; u < B_UNITS; ++u) {
     const int unit = tid + u * kThreads, r = unit >> 1, h = unit & 1;
+    const int row = n0 + r, rc = row < p.N ? row : p.N - 1;
+    b_q[u] = p.B + (size_t)rc * half_k + h * 16;
+    b_sf[u] = p.SFB + sf_atom_offset(rc, 0, atoms_k) + h * 2;
+    b_live[u] = row < p.N ? 0xffffu : 0u;
 #pragma unroll
     for (int j = 0; j < 4; ++j) b_slot[u][j] = kMfma32 ? lds_slot32(r, h * 4 + j) : lds_slot(r, h * 4 + j);
   }
-  auto set_tile = [&](int vb) __attribute__((always_inline)) {
-    int bid = vb;
-    split = 0;
-    if (p.splits > 1) {
-      split = bid / ntiles;
-      bid -= split * ntiles;
-    }
-    {
-      const int q8 = ntiles >> 3, r8 = ntiles & 7, x = bid & 7, j = bid >> 3;
-      bid = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + j;     // bijective for any ntiles
-    }
-    constexpr int kGroupM = 8;
-    const int per_group = kGroupM * p.tiles_n;
-    const int grp = bid / per_group;
-    const int first_m = grp * kGroupM;
-    const int gsz = min(p.tiles_m - first_m, kGroupM);
-    const int tm = first_m + (bid % per_group) % gsz;
-    const int tn = (bid % per_group) / gsz;
-    m0 = tm * BM;
-    n0 = tn * BN;
-    a_begin = split * p.atoms_per_split;
-    a_end = min(atoms_k, a_begin + p.atoms_per_split);   // never empty
-#pragma unroll
-    for (int u = 0; u < A_UNITS; ++u) {
-      const int unit = tid + u * kThreads, r = A_PARTIAL ? min(unit >> 1, BM - 1) : unit >> 1, h = unit & 1;
-      const int row = m0 + r, rc = row < p.M ? row : p.M - 1;
-      a_q[u] = p.A + (size_t)rc * half_k + h * 16;
-      a_sf[u] = p.SFA + sf_atom_offset(rc, 0, atoms_k) + h * 2;
-      a_live[u] = row < p.M ? 0xffffu : 0u;
-    }
-#pragma unroll
-    for (int u = 0; u < B_UNITS; ++u) {
-      const int unit = tid + u * kThreads, r = unit >> 1, h = unit & 1;
-      const int row = n0 + r, rc = row < p.N ? row : p.N - 1;
-      b_q[u] = p.B + (size_t)rc * half_k + h * 16;
-      b_sf[u] = p.SFB + sf_atom_offset(rc, 0, atoms_k) + h * 2;
-      b_live[u] = row < p.N ? 0xffffu : 0u;
-    }
-  };
-  int vb = blockIdx.x;
-  set_tile(vb);
   // fragment read offsets: one base per operand; tile i adds i*16 rows (the swizzle term is invariant under
   // +16 rows) and the second half of K flips bit 2 of the slot index, i.e. byte-offset bit 6
   const int fa_base = kMfma32 ? lds_slot32(wr * WM + (lane & 31), lane >> 5) : lds_slot(wr * WM + (lane & 15), lane >> 4);
   const int fb_base = kMfma32 ? lds_slot32(wc * WN + (lane & 31), lane >> 5) : lds_slot(wc * WN + (lane & 15), lane >> 4);
   acc_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < (kMfma32 ? 16 : 4); ++r) acc[i][j][r] = 0.f;
 
   Staged sa[A_UNITS], sb[B_UNITS];     // registers holding step kt+1 while step kt is multiplied
   auto load_step = [&](int atom) {
@@ -318,19 +304,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
     __syncthreads();
   };
 
-  // the second-dispatched half of an 8-wave workgroup loses every issue arbitration against its SIMD partner at equal
-  // priority; a static priority for it (never flipped) measured +0.8 % (1192-1203 -> 1209-1212 TFLOP/s)
-  if (WAVES_M * WAVES_N == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+  // ---- prologue: tile 0 into buffer 0, registers <- step 1
   load_step(a_begin);
-#pragma unroll 1
-  for (;;) {
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < (kMfma32 ? 16 : 4); ++r) acc[i][j][r] = 0.f;
-  // ---- prologue: step 0 (in registers since before the previous tile's epilogue) into buffer 0, registers <- step 1
   store_step(lds_a0, lds_b0);
   load_step(min(a_begin + 1, a_end - 1));
   if (kStagger && late) {                       // the late group enters the loop with step 1 staged and step 2 in registers
@@ -339,6 +314,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
   }
   __syncthreads();
   int kt = a_begin;
+  // the second-dispatched half of an 8-wave workgroup loses every issue arbitration against its SIMD partner at equal
+  // priority; a static priority for it (never flipped) measured +0.8 % (1192-1203 -> 1209-1212 TFLOP/s)
+  if (WAVES_M * WAVES_N == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
   ARCQ_TILE_STAMP(0);
   if constexpr (kPipe) {
     for (; kt + 1 < a_end; kt += 2) {
@@ -354,16 +332,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
     if (kt < a_end) k_step(kt, lds_a0, lds_b0, lds_a1, lds_b1);
   }
   ARCQ_TILE_STAMP(1);
-
-  // ---- next tile of this workgroup: its first operand loads go out BEFORE this tile's stores (a wave's memory operations
-  //      retire in order: waiting for loads that are OLDER than the stores does not wait for the stores)
-  const int em0 = m0, en0 = n0, esplit = split, evb = vb;
-  vb += (int)gridDim.x;
-  const bool more = vb < nblocks;
-  if (more) {
-    set_tile(vb);
-    load_step(a_begin);
-  }
 
   // ---- epilogue.  16x16 tiles: lane holds D[m = +(lane & 15)][n = +4*(lane >> 4) + r], r = 0..3.
   //      32x32 tiles: lane holds D[m = +(lane & 31)][n = +8*g + 4*(lane >> 5) + r], g = 0..3, r = 0..3.
@@ -385,7 +353,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
       return;
     }
     if (p.splits > 1) {                       // raw partial sums; the launcher only splits when N % 4 == 0
-      *reinterpret_cast<float4*>(p.partial + ((size_t)esplit * p.M + m) * p.N + n) = make_float4(d0, d1, d2, d3);
+      *reinterpret_cast<float4*>(p.partial + ((size_t)split * p.M + m) * p.N + n) = make_float4(d0, d1, d2, d3);
       return;
     }
     float d[4] = {alpha * d0, alpha * d1, alpha * d2, alpha * d3};
@@ -417,15 +385,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       if constexpr (kMfma32) {
-        const int m = em0 + wr * WM + i * 32 + (lane & 31);
+        const int m = m0 + wr * WM + i * 32 + (lane & 31);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int n = en0 + wc * WN + j * 32 + 8 * g + 4 * (lane >> 5);
+          const int n = n0 + wc * WN + j * 32 + 8 * g + 4 * (lane >> 5);
           store4(m, n, acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
         }
       } else {
-        const int m = em0 + wr * WM + i * 16 + (lane & 15);
-        const int n = en0 + wc * WN + j * 16 + 4 * (lane >> 4);
+        const int m = m0 + wr * WM + i * 16 + (lane & 15);
+        const int n = n0 + wc * WN + j * 16 + 4 * (lane >> 4);
         store4(m, n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
       }
     }
@@ -440,10 +408,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
       uint32_t m = 0;
 #pragma unroll
       for (int w = 0; w < WAVES_M * WAVES_N; ++w) m = max(m, wave_max[w]);
-      p.slots[evb] = m;
+      p.slots[blockIdx.x] = m;
     }
-  }
-  if (!more) break;
   }
 }
 
@@ -462,10 +428,6 @@ static void tile_split(int64_t M, int64_t N, int64_t K, int BM, int BN, int* spl
 
 static bool tile_stagger() {                    // ARCQ_TILE_STAGGER=0|1 (tuning)
   static const int v = getenv("ARCQ_TILE_STAGGER") ? atoi(getenv("ARCQ_TILE_STAGGER")) : 0;
-  return v != 0;
-}
-static bool tile_persist() {                    // ARCQ_TILE_PERSIST=0|1 (tuning)
-  static const int v = getenv("ARCQ_TILE_PERSIST") ? atoi(getenv("ARCQ_TILE_PERSIST")) : 1;
   return v != 0;
 }
 static bool tile_pipe() {                       // ARCQ_TILE_PIPE=0|1 (tuning)
@@ -505,11 +467,7 @@ static int launch_tile(const GemmArgs& a, hipStream_t stream, bool allow_split =
   static LdsOptIn lds_opt[3];
   const int which = (kCanPipe && tile_pipe()) ? 1 : (kCanStagger && tile_stagger()) ? 2 : 0;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_opt[which], (int)lds, "arcq_gemm_nvfp4 (tile)")) return rc;
-  // one 8-wave 256x256 workgroup fills a CU: with more blocks than CUs the grid is 256 persistent workgroups (a multiple of 8, see
-  // the kernel's tile order) that walk the blocks; every other configuration keeps one block per workgroup
-  int64_t grid = (int64_t)p.tiles_m * p.tiles_n * p.splits;
-  if (BM == 256 && BN == 256 && WAVES_M * WAVES_N == 8 && which != 2 && grid > 256 && tile_persist()) grid = 256;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES_M * WAVES_N * 64), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n * p.splits)), dim3(WAVES_M * WAVES_N * 64), lds, stream, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_gemm_nvfp4 (tile): launch failed: %s", hipGetErrorString(e));
   if (p.splits > 1) return gemm_splitk_finish(a, p.splits, stream);
