@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""A-B of the persistent tile schedule (ARCQ_TILE_PERSIST=0|1, tuning switch of csrc/gemm_tile.hip): steady-state time per launch of
+"""A-B of the persistent tile schedule (ARCQ_TILE_PERSIST=0|1 -- a tuning switch of csrc/gemm_tile.hip in commit eb436bb only; the
+schedule was removed again, DESIGN.md 3.2, so on the current source both arms run the same kernel): steady-state time per launch of
 agemm.matmul (and of the SiLU*up epilogue variant) on shapes with more than 256 tiles of 256 x 256.  One subprocess per setting
 (the switch is read once per process).  usage: tile_persist_ab.py [M N KQ [silu]] ..."""
 import json
