@@ -175,6 +175,13 @@ __device__ __forceinline__ void asm_wait_behind_units(int units) {
 __device__ __forceinline__ void asm_tie(uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 __device__ __forceinline__ void asm_tie(uint32_t& v) { asm volatile("" : "+v"(v)); }
 
+// lane i <- lane i + N inside its row of 16 lanes, 0.0f beyond the row (__shfl_down for the last four levels of a tree whose root
+// is lane 0, without the LDS crossbar)
+template <int N>
+__device__ __forceinline__ float dpp_row_shl(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, true));
+}
+
 template <int kSrc, int kOut, int kVariant>
 __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -227,13 +234,13 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
     // every asm load is UNCONDITIONAL (a conditionally defined register is merged with its default by a copy -- of a register
     // whose load is still in flight): operands that are not needed are clamped to something valid and ignored later
     {
-      const int total = p.M * chunks;
-#pragma unroll
-      for (int j = 0; j < kPre; ++j) {
-        const int c = min(tid + j * kStThreads, total - 1);
-        pre_q[j] = asm_load_b128(p.X + (size_t)c * 8);
-        pre_s[j] = 0;
-      }
+      // virtual thread t < M * KQ/16 owns chunks v and KQ/16 + v of row m = t / (KQ/16): the pair whose 16 squares the
+      // reference's RMSNorm adds sequentially (rmsnorm.cu:113-131), so the sum of squares is formed from these registers
+      const int bdx = chunks >> 1;
+      const int vt = min(tid, p.M * bdx - 1), m = vt / bdx, v = vt - m * bdx;
+      pre_q[0] = asm_load_b128(p.X + ((size_t)m * chunks + v) * 8);
+      pre_q[1] = asm_load_b128(p.X + ((size_t)m * chunks + bdx + v) * 8);
+      pre_s[0] = pre_s[1] = 0;
       if constexpr (kSrc == kSrcRms) pre_wn = asm_load_b128(p.Wn + (size_t)min(tid, chunks - 1) * 8);
     }
     {                                                        // reorder_index of this thread's first group
@@ -297,29 +304,41 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
                      *reinterpret_cast<const uint32_t*>(p.SFA + sf_atom_offset(m, cc >> 1, atoms_k)));
     }
   } else {
-    // ---- (a) stage X (and the norm weight) in LDS; abs-max of X on the way (kSrcDyn without abs-max words)
+    // ---- (a) stage X (and the norm weight) in LDS; on the way: abs-max of X (kSrcDyn without abs-max words) or the per-thread
+    //      sums of squares in the reference's association order (kSrcRms: virtual thread v adds the 16 squares of chunks v and
+    //      bdx + v sequentially, rmsnorm.cu:113-131; oracle rms_sumsq)
     uint32_t amax = 0;
-    if (p.stage) {
-      const int total = p.M * chunks;
+    {
+      const int bdx = chunks >> 1, vthreads = p.M * bdx;
+      const bool need = p.stage || kSrc == kSrcRms || (kSrc == kSrcDyn && !p.in_slots);
+      if (need) {
+        for (int t = tid; t < vthreads; t += kStThreads) {
+          const int m = t / bdx, v = t - m * bdx;
+          uint4 d0 = pre_q[0], d1 = pre_q[1];
+          if (t != tid) {                                      // beyond the prefetch (M * KQ > 16 K elements)
+            d0 = *reinterpret_cast<const uint4*>(p.X + ((size_t)m * chunks + v) * 8);
+            d1 = *reinterpret_cast<const uint4*>(p.X + ((size_t)m * chunks + bdx + v) * 8);
+          }
+          if (p.stage) {
+            uint16_t* row = reinterpret_cast<uint16_t*>(xstage + (size_t)m * p.xrow_bytes);
+            lds_store_chunk(row, v, d0);
+            lds_store_chunk(row, bdx + v, d1);
+          }
+          if (kSrc == kSrcDyn) amax = absmax_bits_chunk(d1, absmax_bits_chunk(d0, amax));
+          if (kSrc == kSrcRms) {
+            const uint32_t w8[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            float acc = 0.0f;
 #pragma unroll
-      for (int j = 0; j < kPre; ++j) {
-        const int cc = tid + j * kStThreads;
-        if (cc < total) {
-          const int m = cc / chunks;
-          lds_store_chunk(reinterpret_cast<uint16_t*>(xstage + (size_t)m * p.xrow_bytes), cc - m * chunks, pre_q[j]);
-          if (kSrc == kSrcDyn) amax = absmax_bits_chunk(pre_q[j], amax);
+            for (int j = 0; j < 8; ++j) {
+              const float a = bf16_bits_to_f32(w8[j] & 0xffffu), b = bf16_bits_to_f32(w8[j] >> 16);
+              acc = acc + a * a;
+              acc = acc + b * b;
+            }
+            scratch[m * 512 + v] = acc;
+          }
         }
       }
-      for (int cc = tid + kPre * kStThreads; cc < total; cc += kStThreads) {
-        const int m = cc / chunks;
-        const uint4 d = *reinterpret_cast<const uint4*>(p.X + (size_t)cc * 8);
-        lds_store_chunk(reinterpret_cast<uint16_t*>(xstage + (size_t)m * p.xrow_bytes), cc - m * chunks, d);
-        if (kSrc == kSrcDyn) amax = absmax_bits_chunk(d, amax);
-      }
       if (kSrc == kSrcRms && tid < chunks) lds_store_chunk(reinterpret_cast<uint16_t*>(xstage + (size_t)p.M * p.xrow_bytes), tid, pre_wn);
-    } else if (kSrc == kSrcDyn && !p.in_slots) {
-      const int total = p.M * chunks;
-      for (int cc = tid; cc < total; cc += kStThreads) amax = absmax_bits_chunk(*reinterpret_cast<const uint4*>(p.X + (size_t)cc * 8), amax);
     }
     float dyn_scale = 1.0f;
     if constexpr (kSrc == kSrcDyn) {
@@ -348,26 +367,8 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
       //      s[v] += s[v + stride], stride = 256 ... 1, evaluated by ONE wave per token without a barrier: lane l holds
       //      s[l + 64 j], j < 8 (absent partners are 0.0f: x + 0.0f is x), strides 256 / 128 / 64 combine its own registers,
       //      32 and below are shuffles (the same scheme as quantize.hip's rms_sumsq_tree, byte-checked against the oracle)
-      __syncthreads();                                       // staged rows visible
       const int bdx = G;
-      for (int t = tid; t < p.M * bdx; t += kStThreads) {
-        const int m = t / bdx, v = t - m * bdx;
-        const uint32_t* row = reinterpret_cast<const uint32_t*>(xstage + (size_t)m * p.xrow_bytes);
-        float acc = 0.0f;
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const int cc = it * bdx + v;
-          const uint32_t* w4 = row + 4 * cc + (cc >> 1);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float a = bf16_bits_to_f32(w4[j] & 0xffffu), b = bf16_bits_to_f32(w4[j] >> 16);
-            acc = acc + a * a;
-            acc = acc + b * b;
-          }
-        }
-        scratch[m * 512 + v] = acc;
-      }
-      __syncthreads();
+      __syncthreads();                                       // staged rows and the per-thread sums visible
       if (wave < p.M) {                                      // M <= 16 = waves: token `wave`
         float s8[8];
 #pragma unroll
@@ -380,8 +381,11 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
         const float up = __shfl_down(z, 32, 64);
         if (lane < 32) z = z + up;                                                    // stride 32
         float val = lane < 32 ? z : 0.0f;
-#pragma unroll
-        for (int sh = 16; sh > 0; sh >>= 1) val += __shfl_down(val, sh, 64);          // lane 0's cone = the reference's
+        val += __shfl_down(val, 16, 64);                                              // lane 0's cone = the reference's
+        val += dpp_row_shl<8>(val);                                                   // strides 8 .. 1 stay inside lane 0's row of 16:
+        val += dpp_row_shl<4>(val);                                                   // DPP (lane i <- lane i + n, 0 beyond the row)
+        val += dpp_row_shl<2>(val);                                                   // instead of four LDS-crossbar permutes
+        val += dpp_row_shl<1>(val);
         if (lane == 0) {
           const float var = val / (float)p.KQ + p.eps;                                // rmsnorm.cu:157
           misc[32 + wave] = (float)(1.0 / sqrt((double)var));                         // oracle assumption A4
