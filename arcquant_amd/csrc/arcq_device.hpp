@@ -74,4 +74,25 @@ __device__ __forceinline__ uint32_t silu_mul_bf16(uint32_t g_bits, uint32_t u_bi
   return f32_to_bf16_bits(sb * bf16_bits_to_f32(u_bits));
 }
 
+// ---- cross-lane helpers on DPP (no LDS crossbar: __shfl_down is a ds_bpermute, ~100 cycles of latency on a pipe the gathers use)
+// lane i <- lane i + N inside its row of 16 lanes, 0 beyond the row
+template <int N>
+__device__ __forceinline__ uint32_t dpp_row_shl_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + N, 0xf, 0xf, true);
+}
+template <int N>
+__device__ __forceinline__ float dpp_row_shl(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, true));
+}
+// max over the 64 lanes of a wave, returned in every lane (a scalar): four DPP levels inside the rows, then the four row heads
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  v = max(v, dpp_row_shl_u32<8>(v));
+  v = max(v, dpp_row_shl_u32<4>(v));
+  v = max(v, dpp_row_shl_u32<2>(v));
+  v = max(v, dpp_row_shl_u32<1>(v));
+  const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+  const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+  return max(max(a, b), max(c, d));
+}
+
 }  // namespace arcq

@@ -175,13 +175,6 @@ __device__ __forceinline__ void asm_wait_behind_units(int units) {
 __device__ __forceinline__ void asm_tie(uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 __device__ __forceinline__ void asm_tie(uint32_t& v) { asm volatile("" : "+v"(v)); }
 
-// lane i <- lane i + N inside its row of 16 lanes, 0.0f beyond the row (__shfl_down for the last four levels of a tree whose root
-// is lane 0, without the LDS crossbar)
-template <int N>
-__device__ __forceinline__ float dpp_row_shl(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, true));
-}
-
 template <int kSrc, int kOut, int kVariant>
 __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -347,8 +340,7 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
         amax = max(max(pre_slot[0], pre_slot[1]), max(pre_slot[2], pre_slot[3]));
         for (int i = tid + 4 * kStThreads; i < p.n_in_slots; i += kStThreads) amax = max(amax, p.in_slots[i]);
       }
-#pragma unroll
-      for (int sh = 32; sh > 0; sh >>= 1) amax = max(amax, (uint32_t)__shfl_down((int)amax, sh, 64));
+      amax = wave_max_u32(amax);
       if (lane == 0) misc_u[wave] = amax;
       __syncthreads();                                       // (also publishes the staged rows)
       uint32_t mbits = 0;
@@ -572,8 +564,7 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
         }
         mx = max(a0 & 0x7fffu, a1 & 0x7fffu);
       }
-#pragma unroll
-      for (int sh = 32; sh > 0; sh >>= 1) mx = max(mx, (uint32_t)__shfl_down((int)mx, sh, 64));
+      mx = wave_max_u32(mx);
       if (lane == 0) p.out_slots[rb] = mx;
     } else {
       if (live) finish4<uint32_t>(p, alpha, rl, n0, sv);
@@ -584,8 +575,7 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
           const uint32_t b2 = f32_to_bf16_bits(alpha * sv[2]), b3 = f32_to_bf16_bits(alpha * sv[3]);
           mx = max(silu_mul_bf16(b0, b1) & 0x7fffu, silu_mul_bf16(b2, b3) & 0x7fffu);
         }
-#pragma unroll
-        for (int sh = 32; sh > 0; sh >>= 1) mx = max(mx, (uint32_t)__shfl_down((int)mx, sh, 64));
+        mx = wave_max_u32(mx);
         if (lane == 0) p.out_slots[rb] = mx;
       }
     }

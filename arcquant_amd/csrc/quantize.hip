@@ -84,8 +84,11 @@ __device__ __forceinline__ float rms_sumsq_tree(float* s, int bdx, float p_lo, f
     const float up = __shfl_down(z, 32, 64);
     if (tid < 32 && tid + 32 < bdx) z = z + up;                        // stride 32
     float val = tid < 32 ? z : 0.0f;
-#pragma unroll
-    for (int sh = 16; sh > 0; sh >>= 1) val += __shfl_down(val, sh, 64);   // lane 0's cone = reference's
+    val += __shfl_down(val, 16, 64);                                       // lane 0's cone = reference's
+    val += dpp_row_shl<8>(val);                                            // strides 8 .. 1 stay inside lane 0's row of 16 (DPP)
+    val += dpp_row_shl<4>(val);
+    val += dpp_row_shl<2>(val);
+    val += dpp_row_shl<1>(val);
     if (tid == 0) s[256] = val;
   }
   __syncthreads();
@@ -138,8 +141,7 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
     } else {
       for (int i = tid; i < nslots; i += kQuantThreads) m = max(m, dyn[i]);
     }
-#pragma unroll
-    for (int sh = 32; sh > 0; sh >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, sh, 64));
+    m = wave_max_u32(m);
     if ((tid & 63) == 0) wave_max[tid >> 6] = m;
     __syncthreads();
     const unsigned int amax_bits = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
@@ -251,9 +253,9 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
         // outside the outlier tail p == g, so the four lanes of a quad own the four bytes of ONE aligned dword of
         // the swizzled scale layout (P and G are multiples of 4): gather them and store once
         uint32_t w = q.s8;
-        w |= (uint32_t)__shfl_down((int)q.s8, 1, 4) << 8;
-        w |= (uint32_t)__shfl_down((int)q.s8, 2, 4) << 16;
-        w |= (uint32_t)__shfl_down((int)q.s8, 3, 4) << 24;
+        w |= dpp_row_shl_u32<1>(q.s8) << 8;                 // the quad's lanes i + 1 .. i + 3 (DPP, not three ds_bpermutes)
+        w |= dpp_row_shl_u32<2>(q.s8) << 16;
+        w |= dpp_row_shl_u32<3>(q.s8) << 24;
         if ((tid & 3) == 0) *reinterpret_cast<uint32_t*>(SF + sf_offset(row, p, K)) = w;
       } else {                                                   // residual: reorder.cu:166-198, 499-550
         GroupQ q = quantize_group<true, kVariant>(v);
@@ -343,8 +345,7 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_contig_dyn_kernel(cons
   const int K = KQ + KE, G = KQ >> 4, P = (KQ - KE) >> 4;
   uint32_t m = 0;
   for (int i = tid; i < nslots; i += kQuantThreads) m = max(m, dyn[i]);
-#pragma unroll
-  for (int sh = 32; sh > 0; sh >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, sh, 64));
+  m = wave_max_u32(m);
   if ((tid & 63) == 0) wave_max[tid >> 6] = m;
   __syncthreads();
   const unsigned int amax_bits = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
@@ -382,9 +383,9 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_contig_dyn_kernel(cons
       GroupQ q = quantize_group<false, kVariant>(v);
       if (live) *reinterpret_cast<uint2*>(qrow + (size_t)p * 8) = q.packed;
       uint32_t sw = q.s8;                                 // the quad's four scale bytes are one aligned dword (P, G multiples of 4)
-      sw |= (uint32_t)__shfl_down((int)q.s8, 1, 4) << 8;
-      sw |= (uint32_t)__shfl_down((int)q.s8, 2, 4) << 16;
-      sw |= (uint32_t)__shfl_down((int)q.s8, 3, 4) << 24;
+      sw |= dpp_row_shl_u32<1>(q.s8) << 8;                   // the quad's lanes i + 1 .. i + 3 (DPP, not three ds_bpermutes)
+      sw |= dpp_row_shl_u32<2>(q.s8) << 16;
+      sw |= dpp_row_shl_u32<3>(q.s8) << 24;
       if (live && (tid & 3) == 0) *reinterpret_cast<uint32_t*>(SF + sf_offset(row, p, K)) = sw;
     } else if (live) {                                    // residual channels: reorder.cu:166-198, 499-550
       GroupQ q = quantize_group<true, kVariant>(v);
@@ -407,8 +408,7 @@ constexpr int kAbsmaxMaxBlocks = 256;    // == ARCQ_DYN_STATE_BYTES / 4
 // workgroup maximum of `m`; valid in thread 0
 __device__ __forceinline__ uint32_t block_max_bits(uint32_t m) {
   __shared__ uint32_t wmax[kAbsmaxThreads / 64];
-#pragma unroll
-  for (int sh = 32; sh > 0; sh >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, sh, 64));
+  m = wave_max_u32(m);
   if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x < 64) {
