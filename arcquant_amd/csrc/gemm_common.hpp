@@ -106,6 +106,27 @@ __device__ __forceinline__ void store_out4(const P& p, int m, int n, const float
   }
 }
 
+// finish4 with the four bias / residual values of (m, n .. n + 3) already in registers (bf16 bits, two per dword; N % 4 == 0):
+// the decode kernels fetch them while their last weights stream instead of after the final barrier
+template <typename Idx, typename P>
+__device__ __forceinline__ void finish4_pre(const P& p, float alpha, int m, int n, const float (&acc)[4], uint2 bias_bits, uint2 res_bits) {
+  const uint32_t bw[2] = {bias_bits.x, bias_bits.y}, rw[2] = {res_bits.x, res_bits.y};
+  float d[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    d[r] = alpha * acc[r];
+    if (p.bias) {
+      const float b = bf16_bits_to_f32((bw[r >> 1] >> (16 * (r & 1))) & 0xffffu);
+      d[r] = (p.out_dtype == ARCQ_OUT_F32 ? d[r] : bf16_bits_to_f32(f32_to_bf16_bits(d[r]))) + b;
+    }
+    if (p.residual) {
+      const float res = bf16_bits_to_f32((rw[r >> 1] >> (16 * (r & 1))) & 0xffffu);
+      d[r] = (p.out_dtype == ARCQ_OUT_F32 ? d[r] : bf16_bits_to_f32(f32_to_bf16_bits(d[r]))) + res;
+    }
+  }
+  store_out4<Idx>(p, m, n, d);
+}
+
 template <typename Idx, typename P>
 __device__ __forceinline__ void finish4(const P& p, float alpha, int m, int n, const float (&acc)[4]) {
   float d[4];

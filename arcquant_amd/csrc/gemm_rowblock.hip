@@ -171,6 +171,16 @@ __global__ __launch_bounds__(kRbThreads, 4) void gemm_rowblock_kernel(RowblockPa
     __builtin_amdgcn_sched_barrier(0);                      // hipcc otherwise sinks all refills to the end of the unrolled body
     ++done;
   };
+  // bias / residual of this wave's output tile (the slice-0 wave finishes the row block): fetched now, behind the ring's first
+  // loads, instead of as a global round trip after the last barrier (N % 4 == 0: 8-byte loads; by-name registers)
+  typedef uint32_t rb_u32x2 __attribute__((ext_vector_type(2)));
+  rb_u32x2 ep_bias = {0, 0}, ep_res = {0, 0};
+  const bool ep_pre = !kSiluAbsmax && (p.N & 3) == 0 && (p.bias || p.residual);
+  if (ep_pre && slice == 0 && active && rl < p.M && rb * 16 + 4 * q < p.N) {
+    const int n0p = rb * 16 + 4 * q;
+    if (p.bias) ep_bias = *reinterpret_cast<const rb_u32x2*>(p.bias + n0p);
+    if (p.residual) ep_res = *reinterpret_cast<const rb_u32x2*>(p.residual + (size_t)rl * p.N + n0p);
+  }
 #pragma unroll 1
   while (done + 3 <= npairs) {
     step(r0);
@@ -193,7 +203,10 @@ __global__ __launch_bounds__(kRbThreads, 4) void gemm_rowblock_kernel(RowblockPa
     }
   }
   const int n0 = rb * 16 + 4 * q;
-  if (active && rl < p.M && n0 < p.N) finish4<uint32_t>(p, alpha, rl, n0, sum);
+  if (active && rl < p.M && n0 < p.N) {
+    if (ep_pre) finish4_pre<uint32_t>(p, alpha, rl, n0, sum, make_uint2(ep_bias.x, ep_bias.y), make_uint2(ep_res.x, ep_res.y));
+    else finish4<uint32_t>(p, alpha, rl, n0, sum);
+  }
   if constexpr (kSiluAbsmax) {                              // N % 4 == 0, bf16 out, no bias / residual (checked by the launcher)
     uint32_t m = 0;
     if (active && rl < p.M && n0 < p.N) {

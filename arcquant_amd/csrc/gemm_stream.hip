@@ -110,6 +110,7 @@ struct StreamParams {
 };
 
 typedef uint32_t st_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t st_u32x2 __attribute__((ext_vector_type(2)));
 struct StreamRegs {           // one unit of this lane: 2 x 16 bytes of codes, 4 scale bytes
   st_u32x4 b0, b1;
   uint32_t s;
@@ -259,6 +260,23 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
     r.b1 = ARCQ_WLOAD(reinterpret_cast<const st_u32x4*>(wp + (size_t)i * 2048 + 1024));
     r.s = ARCQ_WLOAD(reinterpret_cast<const uint32_t*>(sp + (size_t)i * 256));
   };
+  // bias / residual of the (<= 2) row blocks this wave owns, fetched behind its LAST task's loads: they arrive with the last
+  // weights instead of costing a global round trip after the final barrier (plain epilogue, N % 4 == 0: 8-byte loads)
+  st_u32x2 ep_bias0 = {0, 0}, ep_bias1 = {0, 0}, ep_res0 = {0, 0}, ep_res1 = {0, 0};   // by name: a runtime-indexed array lands in scratch
+  const bool ep_pre = kOut == kOutPlain && (p.N & 3) == 0 && (p.bias || p.residual);
+  auto prefetch_epilogue = [&]() __attribute__((always_inline)) {
+    if (!ep_pre) return;
+#pragma unroll
+    for (int seg = 0; seg < 2; ++seg) {
+      const int seg_n = seg == 0 ? len1 : n - len1;
+      if (seg_n <= 0 || (seg == 0 && pa0 != 0)) continue;    // as in the epilogue: not this wave's row block
+      const int n0 = (rb0 + rbl0 + seg) * 16 + 4 * q;
+      if (rl < p.M && n0 < p.N) {
+        if (p.bias) (seg == 0 ? ep_bias0 : ep_bias1) = *reinterpret_cast<const st_u32x2*>(p.bias + n0);
+        if (p.residual) (seg == 0 ? ep_res0 : ep_res1) = *reinterpret_cast<const st_u32x2*>(p.residual + (size_t)rl * p.N + n0);
+      }
+    }
+  };
   const int ntasks = (n + kTask - 1) / kTask;
   int task_left = ntasks, done = 0;
   int c = ntasks > 0 ? (n + ntasks - 1) / ntasks : 0;       // units of the current task (wave-uniform)
@@ -282,6 +300,7 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
   for (int j = 0; j < 4; ++j) asm_tie(pre_slot[j]);
   __builtin_amdgcn_sched_barrier(0);
   ARCQ_STAMP(1);
+  if (ntasks <= 1) prefetch_epilogue();                       // (after the counted wait above: it assumes 3 loads per unit behind it)
 
   // ---- activation image --------------------------------------------------------------------------------------------------
   if constexpr (kSrc == kSrcPacked) {
@@ -508,6 +527,7 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
     if (--task_left > 0) {
       c = (n - done + task_left - 1) / task_left;
       load_task();
+      if (task_left == 1) prefetch_epilogue();
     }
   }
   ARCQ_STAMP(4);
@@ -567,7 +587,13 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
       mx = wave_max_u32(mx);
       if (lane == 0) p.out_slots[rb] = mx;
     } else {
-      if (live) finish4<uint32_t>(p, alpha, rl, n0, sv);
+      if (live) {
+        if (ep_pre) {
+          const st_u32x2 eb = seg == 0 ? ep_bias0 : ep_bias1, er = seg == 0 ? ep_res0 : ep_res1;
+          finish4_pre<uint32_t>(p, alpha, rl, n0, sv, make_uint2(eb.x, eb.y), make_uint2(er.x, er.y));
+        }
+        else finish4<uint32_t>(p, alpha, rl, n0, sv);
+      }
       if constexpr (kOut == kOutSiluAbsmax) {               // N % 4 == 0, bf16 out, no bias / residual (checked by the launcher)
         uint32_t mx = 0;
         if (live) {
