@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
   // bias / residual of the (<= 2) row blocks this wave owns, fetched behind its LAST task's loads: they arrive with the last
   // weights instead of costing a global round trip after the final barrier (plain epilogue, N % 4 == 0: 8-byte loads)
   st_u32x2 ep_bias0 = {0, 0}, ep_bias1 = {0, 0}, ep_res0 = {0, 0}, ep_res1 = {0, 0};   // by name: a runtime-indexed array lands in scratch
-  const bool ep_pre = kOut == kOutPlain && (p.N & 3) == 0 && (p.bias || p.residual);
+  const bool ep_pre = (kOut == kOutPlain || kOut == kOutSiluAct) && (p.N & 3) == 0 && (p.bias || p.residual);
   auto prefetch_epilogue = [&]() __attribute__((always_inline)) {
     if (!ep_pre) return;
 #pragma unroll
@@ -567,10 +567,12 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
       uint32_t mx = 0;
       if (live) {
         uint32_t y[4];                                      // bf16 (gate, up, gate, up) as the separate GEMM (+ bias) would leave them
+        const st_u32x2 eb = seg == 0 ? ep_bias0 : ep_bias1;   // this tile's four bias values, prefetched (N % 4 == 0 here)
+        const uint32_t bw[2] = {eb.x, eb.y};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           y[e] = f32_to_bf16_bits(alpha * sv[e]);
-          if (p.bias) y[e] = f32_to_bf16_bits(bf16_bits_to_f32(y[e]) + bf16_bits_to_f32(p.bias[n0 + e]));
+          if (p.bias) y[e] = f32_to_bf16_bits(bf16_bits_to_f32(y[e]) + bf16_bits_to_f32((bw[e >> 1] >> (16 * (e & 1))) & 0xffffu));
         }
         const uint32_t a0 = silu_mul_bf16(y[0], y[1]);
         const uint32_t a1 = silu_mul_bf16(y[2], y[3]);
