@@ -153,15 +153,34 @@ __global__ __launch_bounds__(kAttnD) void attn_decode_combine(AttnParams p) {
   const int bh = blockIdx.x, d = threadIdx.x;
   const float* w = p.ws + (size_t)bh * p.S * (kAttnD + 2);
   const int T = p.pos + 1 - p.first;
-  float M = -3.0e38f;
-  for (int s = 0; s < p.S; ++s)
-    if (s * p.chunk < T) M = fmaxf(M, w[s * (kAttnD + 2)]);
-  float L = 0.f, a = 0.f;
-  for (int s = 0; s < p.S; ++s) {
-    if (s * p.chunk >= T) break;
-    const float f = __expf(w[s * (kAttnD + 2)] - M);
-    L += w[s * (kAttnD + 2) + 1] * f;
-    a += w[s * (kAttnD + 2) + 2 + d] * f;
+  const int live = min(p.S, (T + p.chunk - 1) / p.chunk);   // slices that hold positions
+  // every slice's (max, sum, accumulator[d]) is requested before anything is combined: ONE global round trip for the launch
+  // (a max pass followed by an accumulate pass was two); 8 slices per batch, more only beyond 2048 cached positions
+  float M = -3.0e38f, L = 0.f, a = 0.f;
+  for (int s0 = 0; s0 < live; s0 += 8) {
+    float ms[8], ls[8], as[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int s = min(s0 + j, live - 1);
+      ms[j] = w[s * (kAttnD + 2)];
+      ls[j] = w[s * (kAttnD + 2) + 1];
+      as[j] = w[s * (kAttnD + 2) + 2 + d];
+    }
+    float Mb = M;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (s0 + j < live) Mb = fmaxf(Mb, ms[j]);
+    const float r = __expf(M - Mb);                          // rescale what earlier batches left (first batch: exp(-inf) = 0 of 0)
+    L *= r;
+    a *= r;
+    M = Mb;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (s0 + j < live) {
+        const float f = __expf(ms[j] - M);
+        L += ls[j] * f;
+        a += as[j] * f;
+      }
   }
   const int b = bh / p.H, h = bh - b * p.H;
   p.out[(size_t)b * p.H * kAttnD + (size_t)h * kAttnD + d] = (uint16_t)f32_to_bf16_bits(a / L);
