@@ -57,6 +57,7 @@ HARNESS_SYMBOLS = {
     "arcq_harness_attn_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "arcq_harness_attn_decode": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "arcq_harness_attn_decode_window": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p]),
+    "arcq_harness_rmsnorm": (_i32, [_p, _i64, _p, _p, _i64, _i64, _f32, _p]),
 }
 
 _lib = None

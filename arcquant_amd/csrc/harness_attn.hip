@@ -186,6 +186,44 @@ __global__ __launch_bounds__(kAttnD) void attn_decode_combine(AttnParams p) {
   p.out[(size_t)b * p.H * kAttnD + (size_t)h * kAttnD + d] = (uint16_t)f32_to_bf16_bits(a / L);
 }
 
+// The model's final RMSNorm (not an ARC operator: the reference uses the stock module there) as ONE launch for the harness: torch's
+// F.rms_norm is ~15 small kernels on this stack, ~40 us of a 2 ms decode step with its index arithmetic.  One workgroup per row,
+// fp32 throughout: out = bf16(float(x) * rsqrt(mean(x^2) + eps) * float(w)).
+__global__ __launch_bounds__(256) void harness_rmsnorm_kernel(const uint16_t* __restrict__ X, int64_t ldx, const uint16_t* __restrict__ W,
+                                                                 uint16_t* __restrict__ out, int H, float eps) {
+  __shared__ float wsum[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const uint16_t* x = X + (size_t)row * ldx;
+  float acc = 0.f;
+  for (int c = tid; c < (H >> 3); c += 256) {
+    const uint4 d = *reinterpret_cast<const uint4*>(x + (size_t)c * 8);
+    const uint32_t w4[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = bf16_bits_to_f32(w4[j] & 0xffffu), b = bf16_bits_to_f32(w4[j] >> 16);
+      acc += a * a + b * b;
+    }
+  }
+#pragma unroll
+  for (int sh = 32; sh > 0; sh >>= 1) acc += __shfl_xor(acc, sh, 64);
+  if ((tid & 63) == 0) wsum[tid >> 6] = acc;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf((wsum[0] + wsum[1] + wsum[2] + wsum[3]) / (float)H + eps);
+  for (int c = tid; c < (H >> 3); c += 256) {
+    const uint4 d = *reinterpret_cast<const uint4*>(x + (size_t)c * 8);
+    const uint4 g = *reinterpret_cast<const uint4*>(W + (size_t)c * 8);
+    const uint32_t w4[4] = {d.x, d.y, d.z, d.w}, g4[4] = {g.x, g.y, g.z, g.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = bf16_bits_to_f32(w4[j] & 0xffffu) * rstd * bf16_bits_to_f32(g4[j] & 0xffffu);
+      const float b = bf16_bits_to_f32(w4[j] >> 16) * rstd * bf16_bits_to_f32(g4[j] >> 16);
+      o[j] = f32_to_bf16_bits(a) | (f32_to_bf16_bits(b) << 16);
+    }
+    *reinterpret_cast<uint4*>(out + (size_t)row * H + (size_t)c * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 }  // namespace arcq
 
 using namespace arcq;
@@ -229,6 +267,21 @@ extern "C" int arcq_harness_attn_decode_window(const void* qkv, void* kcache, vo
   const int live = (T + chunk - 1) / chunk;
   hipLaunchKernelGGL(attn_decode_partial, dim3((unsigned)(B * H), (unsigned)live), dim3(kAttnThreads), 0, (hipStream_t)stream, p);
   if (live > 1) hipLaunchKernelGGL(attn_decode_combine, dim3((unsigned)(B * H)), dim3(kAttnD), 0, (hipStream_t)stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "%s: launch failed: %s", who, hipGetErrorString(e));
+  return ARCQ_OK;
+}
+
+// HARNESS ONLY: out[r, :] = rmsnorm(X[r, :]) * W for `rows` rows of H bf16 values (row stride ldx elements), one launch.
+extern "C" int arcq_harness_rmsnorm(const void* X, int64_t ldx, const void* W, void* out, int64_t rows, int64_t H, float eps, void* stream) {
+  const char* who = "arcq_harness_rmsnorm";
+  if (rows < 0 || H <= 0 || (H % 8) || ldx < H || (ldx % 8)) return fail(ARCQ_ERR_SHAPE, "%s: need H %% 8 == 0, ldx >= H, ldx %% 8 == 0", who);
+  if (rows == 0) return ARCQ_OK;
+  if (!X || !W || !out) return fail(ARCQ_ERR_NULL, "%s: NULL pointer", who);
+  if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(out)) & 15)
+    return fail(ARCQ_ERR_SHAPE, "%s: pointers must be 16-byte aligned", who);
+  hipLaunchKernelGGL(harness_rmsnorm_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X, ldx, (const uint16_t*)W,
+                     (uint16_t*)out, (int)H, eps);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "%s: launch failed: %s", who, hipGetErrorString(e));
   return ARCQ_OK;

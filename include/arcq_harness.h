@@ -30,6 +30,10 @@ int arcq_harness_attn_decode(const void *qkv, void *kcache, void *vcache, void *
 int arcq_harness_attn_decode_window(const void *qkv, void *kcache, void *vcache, void *out, void *workspace, int64_t B, int64_t H,
                                     int64_t Tmax, int64_t pos, int64_t first, void *stream);
 
+/* The model's final RMSNorm (a stock module in the reference, not an ARC operator) in one launch: out[r, :] = bf16(float(X[r, :]) *
+ * rsqrt(mean(X[r, :]^2) + eps) * float(W)), rows of H bf16 values with row stride ldx elements (H % 8 == 0). */
+int arcq_harness_rmsnorm(const void *X, int64_t ldx, const void *W, void *out, int64_t rows, int64_t H, float eps, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -205,3 +205,23 @@ def test_harness_decode_attention_window_is_the_current_token():
         want = want.transpose(1, 2).reshape(bsz, h)
         err = float((out.float() - want).abs().max())
         assert err <= 2.0 ** -7 * float(want.abs().max()) + 1e-3, (first, pos, err)
+
+
+def test_harness_final_rmsnorm_matches_torch():
+    """The harness's one-launch final RMSNorm (include/arcq_harness.h; a stock module in the reference, not an ARC operator) against
+    an fp64 statement of the same formula: bf16 rounding of the exact value (<= 1 ulp), strided rows as the prefill's last-token
+    slice has them."""
+    from arcquant_amd import _lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(9)
+    for rows, H, ld_mult in ((4, 3584, 1), (4, 3584, 1024), (1, 4096, 1), (7, 512, 3)):
+        full = (torch.randn(rows, ld_mult, H, generator=g, device=dev) * 3).to(torch.bfloat16)
+        x = full[:, -1]                                                # [rows, H], row stride ld_mult * H
+        w = (torch.rand(H, generator=g, device=dev) + 0.5).to(torch.bfloat16)
+        out = torch.empty((rows, H), dtype=torch.bfloat16, device=dev)
+        st = _lib.lib().arcq_harness_rmsnorm(x.data_ptr(), x.stride(0), w.data_ptr(), out.data_ptr(), rows, H, 1e-6, torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(st, "harness rmsnorm")
+        xd = x.double()
+        want = xd * torch.rsqrt((xd * xd).mean(-1, keepdim=True) + 1e-6) * w.double()
+        err = (out.double() - want).abs()
+        assert bool((err <= want.abs() * 2.0 ** -7 + 1e-30).all()), (rows, H, float(err.max()))
