@@ -70,8 +70,10 @@ __device__ __forceinline__ uint32_t silu_act_elem(const uint16_t* g, const uint1
 // v = tid and v = tid + 256); then the fixed tree s[v] += s[v + stride], stride = 256 ... 32, and a 32-lane shuffle.
 // The same tree with TWO barriers instead of seven: the stride-256 step adds two values this thread computed itself;
 // strides 128 and 64 only ever feed s[0..63], so wave 0 evaluates them for its 64 columns from four LDS reads;
-// stride 32 and below are shuffles.  `s` is an LDS array of >= 512 floats.  Returns the total in every thread.
-__device__ __forceinline__ float rms_sumsq_tree(float* s, int bdx, float p_lo, float p_hi) {
+// stride 32 and below are shuffles.  `s` is an LDS array of >= 512 floats.  Returns rstd = 1 / sqrt(total / KQ + eps) in every
+// thread: thread 0 forms it (the correctly rounded double-precision evaluation is ~35 half-rate instructions -- done by all 256
+// threads of all resident workgroups it was ~2 us of the 18.5 us launch at 4096 x 4096) and publishes it with the second barrier.
+__device__ __forceinline__ float rms_rstd_tree(float* s, int bdx, float p_lo, float p_hi, int KQ, float eps) {
   const int tid = threadIdx.x;
   const float s256 = (tid + 256 < bdx) ? p_lo + p_hi : p_lo;           // stride 256
   if (tid < bdx) s[tid] = s256;
@@ -89,7 +91,10 @@ __device__ __forceinline__ float rms_sumsq_tree(float* s, int bdx, float p_lo, f
     val += dpp_row_shl<4>(val);
     val += dpp_row_shl<2>(val);
     val += dpp_row_shl<1>(val);
-    if (tid == 0) s[256] = val;
+    if (tid == 0) {
+      const float var = val / (float)KQ + eps;                             // rmsnorm.cu:157
+      s[256] = (float)(1.0 / sqrt((double)var));                           // oracle assumption A4
+    }
   }
   __syncthreads();
   return s[256];
@@ -206,9 +211,7 @@ __global__ __launch_bounds__(kQuantThreads) void quantize_rows_kernel(
           part[k] = acc;
         }
       }
-      float sum = rms_sumsq_tree(red, bdx, part[0], part[1]);
-      float var = sum / (float)KQ + eps;                       // rmsnorm.cu:157
-      rstd = (float)(1.0 / sqrt((double)var));                 // oracle assumption A4
+      rstd = rms_rstd_tree(red, bdx, part[0], part[1], KQ, eps);
     } else {
       if (kSilu && gridDim.y > 1) {
         // decode-sized silu*up: a staged row would be recomputed (one exp per element) by each of the gridDim.y
