@@ -200,7 +200,9 @@ int arcq_silu_mul_quantize_x_dyn_slots(const void *GU, const int16_t *reorder_in
  * workgroup quantises the M <= 16 token rows itself with the quantisers' own group arithmetic, so the result is BIT-IDENTICAL
  * to arcq_rmsnorm_quantize_x / arcq_quantize_x_dyn followed by arcq_gemm_nvfp4_repacked on the same repacked weight.
  * arcq_linear_fused_supported(kind, M, N, KQ, KE) tells whether a shape fits (M <= 16, LDS); callers fall back to the two
- * calls otherwise. */
+ * calls otherwise.  It is a capability, not a recommendation: every CU repeats the quantisation of all M * KQ elements, which beats
+ * the separate quantiser launch (~3 us of launch + cold start) while M * KQ is about 16 K elements or less (measured on MI355X:
+ * M = 4, KQ = 3584 / 4096: 1-2 us faster per linear; M = 16, KQ = 4096 or M = 4, KQ = 18944: 2-3x slower). */
 #define ARCQ_SRC_RMSNORM 1
 #define ARCQ_SRC_DYNAMIC 2
 int arcq_linear_fused_supported(int kind, int64_t M, int64_t N, int64_t KQ, int64_t KE);
