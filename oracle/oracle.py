@@ -21,7 +21,7 @@ G16 = 0  # one 16-group per thread: reorder.cu:68-330, rmsnorm.cu:68-255
 G32 = 1  # two 16-groups per thread: reorder.cu:380-696, down.cu:71-361
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libarcq_oracle.so")
+_SO = os.environ.get("ARCQ_ORACLE_LIB") or os.path.join(_HERE, "_build", "libarcq_oracle.so")   # override: the sanitizer build (make asan)
 _lib = None
 
 
