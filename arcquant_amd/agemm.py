@@ -23,8 +23,36 @@ from . import _lib
 from ._lib import VARIANT_G16, VARIANT_G32, OUT_BF16, OUT_F32, ArcqError  # noqa: F401  (re-exported)
 
 
+import functools
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(t: torch.Tensor) -> int:
+    # the current HIP stream of the tensor's device as an integer handle.  The private accessor (what torch's own extensions use)
+    # saves ~1.5 us per call over building a torch.cuda.Stream object; an eager decode step makes ~170 of these calls and is
+    # host-paced (tools/host_overhead.py)
+    if _raw_stream is not None:
+        return _raw_stream(t.device.index if t.device.index is not None else torch.cuda.current_device())
     return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class _on:
+    """``with _on(device):`` -- torch.cuda.device(device), but free when the device is already current (the usual case)."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, device):
+        idx = device.index
+        self.ctx = None if idx is None or idx == torch.cuda.current_device() else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*exc)
+        return False
 
 
 def _need(t: torch.Tensor, dtype, name: str, ndim=None):
@@ -39,14 +67,27 @@ def _need(t: torch.Tensor, dtype, name: str, ndim=None):
         raise RuntimeError(f"agemm: {name} must be contiguous")
 
 
+@functools.lru_cache(maxsize=None)
 def variant_for_kq(KQ: int) -> int:
     """Layout variant the reference's dispatch picks for this in_features (bindings.cpp:141-160)."""
     return int(_lib.lib().arcq_variant_for_kq(int(KQ)))
 
 
+@functools.lru_cache(maxsize=None)
 def sf_buffer_bytes(rows: int, K: int) -> int:
     """get_sf{a,b}_buffer_size_in_bytes (bindings.cpp:83-95)."""
     return int(_lib.lib().arcq_sf_alloc_bytes(int(rows), int(K)))
+
+
+@functools.lru_cache(maxsize=None)
+def _sf_used(rows: int, K: int) -> int:
+    return int(_lib.lib().arcq_sf_used_bytes(int(rows), int(K)))
+
+
+@functools.lru_cache(maxsize=None)
+def _repacked_bytes(N: int, K: int):
+    L = _lib.lib()
+    return int(L.arcq_repacked_w_bytes(N, K)), int(L.arcq_repacked_sf_bytes(N, K))
 
 
 def _quantize(fn_name: str, X: torch.Tensor, reorder_index: torch.Tensor, KE: int, variant):
@@ -65,7 +106,7 @@ def _quantize(fn_name: str, X: torch.Tensor, reorder_index: torch.Tensor, KE: in
     SF = torch.empty((sf_buffer_bytes(rows, K),), dtype=torch.uint8, device=X.device)
     L = _lib.lib()
     fn = L.arcq_quantize_x if fn_name.endswith("_x") else L.arcq_quantize_w
-    with torch.cuda.device(X.device):
+    with _on(X.device):
         st = fn(X.data_ptr(), reorder_index.data_ptr(), Q.data_ptr(), SF.data_ptr(), rows, KQ, KE, int(variant), _stream(X))
     _lib.check(st, fn_name)
     return Q, SF
@@ -98,7 +139,7 @@ def rmsnorm_quantize_x(X: torch.Tensor, W: torch.Tensor, eps: float, reorder_ind
         raise RuntimeError(f"Value error in run_rmsnorm_x_bf16_nvfp4: K value is not valid: {KQ}")
     QX = torch.empty((M, K // 2), dtype=torch.uint8, device=X.device)
     SFX = torch.empty((sf_buffer_bytes(M, K),), dtype=torch.uint8, device=X.device)
-    with torch.cuda.device(X.device):
+    with _on(X.device):
         st = _lib.lib().arcq_rmsnorm_quantize_x(X.data_ptr(), W.data_ptr(), float(eps), reorder_index.data_ptr(), QX.data_ptr(),
                                                 SFX.data_ptr(), M, KQ, KE, int(variant), _stream(X))
     _lib.check(st, "rmsnorm_quantize_x")
@@ -123,7 +164,7 @@ def matmul(A: torch.Tensor, B: torch.Tensor, SFA: torch.Tensor, SFB: torch.Tenso
     if B.shape[1] * 2 != K:
         raise RuntimeError(f"agemm.matmul: A has K={K}, B has K={B.shape[1] * 2}")
     L = _lib.lib()
-    if SFA.numel() < L.arcq_sf_used_bytes(M, K) or SFB.numel() < L.arcq_sf_used_bytes(N, K):
+    if SFA.numel() < _sf_used(M, K) or SFB.numel() < _sf_used(N, K):
         raise RuntimeError("agemm.matmul: scale-factor buffer smaller than the swizzled layout of its operand")
     alpha_host, alpha_dev = float(scale_host), None
     if isinstance(scale, torch.Tensor):
@@ -151,7 +192,7 @@ def matmul(A: torch.Tensor, B: torch.Tensor, SFA: torch.Tensor, SFB: torch.Tenso
             raise RuntimeError("agemm.matmul: residual must be [M, N]")
     ws_bytes = int(L.arcq_gemm_workspace_bytes(M, N, K))
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=A.device) if ws_bytes else None
-    with torch.cuda.device(A.device):
+    with _on(A.device):
         st = L.arcq_gemm_nvfp4(A.data_ptr(), B.data_ptr(), SFA.data_ptr(), SFB.data_ptr(), out.data_ptr(), M, N, K,
                                alpha_host, alpha_dev.data_ptr() if alpha_dev is not None else None,
                                bias.data_ptr() if bias is not None else None,
@@ -168,7 +209,7 @@ def absmax_scale(X: torch.Tensor) -> torch.Tensor:
     ``x / scale`` keeps x's dtype exactly as with the reference's scalar tensor)."""
     _need(X, torch.bfloat16, "X")
     out = torch.empty((1,), dtype=torch.float32, device=X.device)
-    with torch.cuda.device(X.device):
+    with _on(X.device):
         st = _lib.lib().arcq_absmax_scale(X.data_ptr(), X.numel(), out.data_ptr(), _stream(X))
     _lib.check(st, "absmax_scale")
     return out.reshape(())
@@ -208,7 +249,7 @@ def _quantize_dynamic(entry: str, who: str, X: torch.Tensor, KQ: int, reorder_in
     QX = torch.empty((M, K // 2), dtype=torch.uint8, device=dev)
     SFX = torch.empty((sf_buffer_bytes(M, K),), dtype=torch.uint8, device=dev)
     scale = torch.empty((1,), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         if slots is not None and layout is not None:
             st = getattr(_lib.lib(), entry)(X.data_ptr(), reorder_index.data_ptr(), QX.data_ptr(), SFX.data_ptr(), scale.data_ptr(),
                                             slots.data_ptr(), slots.numel(), M, KQ, KE, int(variant), int(layout), _stream(X))
@@ -233,7 +274,7 @@ def repack_w(QW: torch.Tensor, SFW: torch.Tensor):
     _need(QW, torch.uint8, "QW", 2)
     _need(SFW, torch.uint8, "SFW", 1)
     N, K = QW.shape[0], QW.shape[1] * 2
-    if K % 64 or SFW.numel() < _lib.lib().arcq_sf_used_bytes(N, K):
+    if K % 64 or SFW.numel() < _sf_used(N, K):
         raise RuntimeError("Value error in repack_w: K % 64 != 0 or the scale buffer is too small")
     dev = QW.device
     Np, Kp = (N + 15) // 16 * 16, (K + 255) // 256 * 256
@@ -255,6 +296,7 @@ def repack_w(QW: torch.Tensor, SFW: torch.Tensor):
     return RW, RSF
 
 
+@functools.lru_cache(maxsize=None)
 def repacked_supported(M: int, N: int, K: int) -> bool:
     """Whether ``matmul_repacked`` can run this shape (M <= 16 and the fp16 image of the activations fits LDS)."""
     return bool(_lib.lib().arcq_gemm_repacked_supported(int(M), int(N), int(K)))
@@ -271,11 +313,11 @@ def matmul_repacked(A: torch.Tensor, RW: torch.Tensor, SFA: torch.Tensor, RSF: t
     _need(RSF, torch.uint8, "RSF", 1)
     M, K, N = A.shape[0], A.shape[1] * 2, int(N)
     L = _lib.lib()
-    if K % 64 or RW.numel() != L.arcq_repacked_w_bytes(N, K) or RSF.numel() != L.arcq_repacked_sf_bytes(N, K):
+    if K % 64 or (RW.numel(), RSF.numel()) != _repacked_bytes(N, K):
         raise RuntimeError(f"Value error in matmul_repacked: RW / RSF do not belong to a [{N}, {K}] weight")
-    if SFA.numel() < L.arcq_sf_used_bytes(M, K):
+    if SFA.numel() < _sf_used(M, K):
         raise RuntimeError("Value error in matmul_repacked: SFA smaller than the swizzled layout of A")
-    if not L.arcq_gemm_repacked_supported(M, N, K):
+    if not repacked_supported(M, N, K):
         raise RuntimeError(f"matmul_repacked: M={M}, K={K} is outside the repacked path (see repacked_supported)")
     if out_dtype not in (torch.bfloat16, torch.float32):
         raise RuntimeError("agemm.matmul_repacked: out_dtype must be bfloat16 or float32")
@@ -299,7 +341,7 @@ def matmul_repacked(A: torch.Tensor, RW: torch.Tensor, SFA: torch.Tensor, RSF: t
     # kernel="stream": the kernel body of the fused decode linears (rmsnorm_matmul_repacked, dynamic_matmul_repacked), so that
     # quantiser + this call is their bit-exact two-launch equivalent; "auto" = the fastest kernel for plain packed activations
     fn = L.arcq_gemm_nvfp4_repacked_stream if kernel == "stream" else L.arcq_gemm_nvfp4_repacked
-    with torch.cuda.device(A.device):
+    with _on(A.device):
         st = fn(A.data_ptr(), RW.data_ptr(), SFA.data_ptr(), RSF.data_ptr(), out.data_ptr(), M, N, K, alpha_host,
                                         alpha_dev.data_ptr() if alpha_dev is not None else None,
                                         bias.data_ptr() if bias is not None else None,
@@ -321,7 +363,7 @@ def matmul_silu_mul(A: torch.Tensor, B: torch.Tensor, SFA: torch.Tensor, SFB: to
     M, N, K = A.shape[0], B.shape[0], A.shape[1] * 2
     if B.shape[1] != A.shape[1] or K % 64 or N % 8:
         raise RuntimeError(f"Value error in matmul_silu_mul: A {tuple(A.shape)} / B {tuple(B.shape)} need equal K, K % 64 == 0, N % 8 == 0")
-    if SFA.numel() < _lib.lib().arcq_sf_used_bytes(M, K) or SFB.numel() < _lib.lib().arcq_sf_used_bytes(N, K):
+    if SFA.numel() < _sf_used(M, K) or SFB.numel() < _sf_used(N, K):
         raise RuntimeError("Value error in matmul_silu_mul: scale buffer too small")
     alpha_host, alpha_dev = float(scale_host), None
     if isinstance(scale, torch.Tensor) and scale.is_cuda:
@@ -331,7 +373,7 @@ def matmul_silu_mul(A: torch.Tensor, B: torch.Tensor, SFA: torch.Tensor, SFB: to
     L = _lib.lib()
     act = torch.empty((M, N // 2), dtype=torch.bfloat16, device=A.device)
     slots = torch.empty((max(1, int(L.arcq_gemm_silu_mul_slots(M, N, K))),), dtype=torch.int32, device=A.device)
-    with torch.cuda.device(A.device):
+    with _on(A.device):
         st = L.arcq_gemm_nvfp4_silu_mul(A.data_ptr(), B.data_ptr(), SFA.data_ptr(), SFB.data_ptr(), act.data_ptr(), slots.data_ptr(), M, N, K,
                                         alpha_host, alpha_dev.data_ptr() if alpha_dev is not None else None,
                                         _opt(bias, torch.bfloat16, "bias", (N,)), _stream(A))
@@ -388,11 +430,11 @@ def matmul_repacked_silu_absmax(A: torch.Tensor, RW: torch.Tensor, SFA: torch.Te
     _need(RSF, torch.uint8, "RSF", 1)
     M, K, N = A.shape[0], A.shape[1] * 2, int(N)
     L = _lib.lib()
-    if K % 64 or N % 4 or RW.numel() != L.arcq_repacked_w_bytes(N, K) or RSF.numel() != L.arcq_repacked_sf_bytes(N, K):
+    if K % 64 or N % 4 or (RW.numel(), RSF.numel()) != _repacked_bytes(N, K):
         raise RuntimeError(f"Value error in matmul_repacked_silu_absmax: RW / RSF do not belong to a [{N}, {K}] weight, or N % 4 != 0")
-    if SFA.numel() < L.arcq_sf_used_bytes(M, K):
+    if SFA.numel() < _sf_used(M, K):
         raise RuntimeError("Value error in matmul_repacked_silu_absmax: SFA smaller than the swizzled layout of A")
-    if not L.arcq_gemm_repacked_supported(M, N, K):
+    if not repacked_supported(M, N, K):
         raise RuntimeError(f"matmul_repacked_silu_absmax: M={M}, K={K} is outside the repacked path (see repacked_supported)")
     alpha_host, alpha_dev = float(scale_host), None
     if isinstance(scale, torch.Tensor) and scale.is_cuda and scale.dtype == torch.float32 and scale.numel() == 1:
@@ -404,7 +446,7 @@ def matmul_repacked_silu_absmax(A: torch.Tensor, RW: torch.Tensor, SFA: torch.Te
     elif tuple(out.shape) != (M, N) or out.dtype != torch.bfloat16 or not out.is_contiguous():
         raise RuntimeError("agemm.matmul_repacked_silu_absmax: out has the wrong shape / dtype")
     slots = torch.empty(((N + 15) // 16,), dtype=torch.int32, device=A.device)
-    with torch.cuda.device(A.device):
+    with _on(A.device):
         st = L.arcq_gemm_nvfp4_repacked_silu_absmax(A.data_ptr(), RW.data_ptr(), SFA.data_ptr(), RSF.data_ptr(), out.data_ptr(),
                                                     slots.data_ptr(), M, N, K, alpha_host,
                                                     alpha_dev.data_ptr() if alpha_dev is not None else None, _stream(A))
@@ -415,6 +457,7 @@ def matmul_repacked_silu_absmax(A: torch.Tensor, RW: torch.Tensor, SFA: torch.Te
 SRC_RMSNORM, SRC_DYNAMIC = 1, 2
 
 
+@functools.lru_cache(maxsize=None)
 def fused_supported(kind: int, M: int, N: int, KQ: int, KE: int) -> bool:
     """Whether the fused decode linear (activation quantiser as the GEMM prologue) can run this shape: M <= 16 and the LDS
     budget of one CU.  ``kind``: SRC_RMSNORM or SRC_DYNAMIC.  Callers fall back to the separate calls otherwise."""
@@ -432,7 +475,7 @@ def _fused_common(who, X, reorder_index, RW, RSF, N, KE, variant):
     L = _lib.lib()
     if KQ % 64 or KE % 64 or KE < 0 or KE > KQ or reorder_index.numel() != KQ:
         raise RuntimeError(f"Value error in {who}: KQ={KQ}, KE={KE} is not valid")
-    if RW.numel() != L.arcq_repacked_w_bytes(N, K) or RSF.numel() != L.arcq_repacked_sf_bytes(N, K):
+    if (RW.numel(), RSF.numel()) != _repacked_bytes(N, K):
         raise RuntimeError(f"Value error in {who}: RW / RSF do not belong to a [{N}, {K}] weight")
     if variant is None:
         variant = variant_for_kq(KQ)
@@ -469,7 +512,7 @@ def rmsnorm_matmul_repacked(X: torch.Tensor, W: torch.Tensor, eps: float, reorde
         out = torch.empty((M, N), dtype=out_dtype, device=X.device)
     elif tuple(out.shape) != (M, N) or out.dtype != out_dtype or not out.is_contiguous():
         raise RuntimeError("agemm.rmsnorm_matmul_repacked: out has the wrong shape / dtype")
-    with torch.cuda.device(X.device):
+    with _on(X.device):
         st = _lib.lib().arcq_linear_rmsnorm_repacked(X.data_ptr(), W.data_ptr(), float(eps), reorder_index.data_ptr(), RW.data_ptr(), RSF.data_ptr(),
                                                      out.data_ptr(), M, N, KQ, KE, variant, alpha_host,
                                                      alpha_dev.data_ptr() if alpha_dev is not None else None,
@@ -500,7 +543,7 @@ def rmsnorm_matmul_repacked_silu(X: torch.Tensor, W: torch.Tensor, eps: float, r
         alpha_host *= float(scale)
     act = torch.empty((M, N // 2), dtype=torch.bfloat16, device=X.device)
     slots = torch.empty(((N + 15) // 16,), dtype=torch.int32, device=X.device)
-    with torch.cuda.device(X.device):
+    with _on(X.device):
         st = _lib.lib().arcq_linear_rmsnorm_silu_repacked(X.data_ptr(), W.data_ptr(), float(eps), reorder_index.data_ptr(), RW.data_ptr(),
                                                           RSF.data_ptr(), act.data_ptr(), slots.data_ptr(), M, N, KQ, KE, variant, alpha_host,
                                                           alpha_dev.data_ptr() if alpha_dev is not None else None,
@@ -529,7 +572,7 @@ def dynamic_matmul_repacked(X: torch.Tensor, reorder_index: torch.Tensor, KE: in
     elif tuple(out.shape) != (M, N) or out.dtype != out_dtype or not out.is_contiguous():
         raise RuntimeError("agemm.dynamic_matmul_repacked: out has the wrong shape / dtype")
     scale = torch.empty((1,), dtype=torch.float32, device=X.device)
-    with torch.cuda.device(X.device):
+    with _on(X.device):
         st = _lib.lib().arcq_linear_dynamic_repacked(X.data_ptr(), reorder_index.data_ptr(), RW.data_ptr(), RSF.data_ptr(), out.data_ptr(),
                                                      scale.data_ptr(), absmax_slots.data_ptr() if absmax_slots is not None else None,
                                                      absmax_slots.numel() if absmax_slots is not None else 0, M, N, KQ, KE, variant,
