@@ -655,6 +655,7 @@ static int stream_geometry(int src, int64_t M, int64_t N, int64_t K, int64_t KQ,
 
 int gemm_fused_supported(int kind, int64_t M, int64_t N, int64_t KQ, int64_t KE) {
   StreamGeom g;
+  if (kind != kSrcRms && kind != kSrcDyn) return 0;
   if (KQ <= 0 || (KQ % 64) || (KE % 64) || KE < 0 || KE > KQ || KQ > 32767) return 0;
   if (kind == kSrcRms && (KQ < 2048 || KQ > 8192)) return 0;
   return stream_geometry(kind, M, N, KQ + KE, KQ, &g);

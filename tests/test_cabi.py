@@ -71,3 +71,39 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert L.arcq_rmsnorm_quantize_x(None, None, 1e-6, None, None, None, 4, 1024, 0, 0, None) == -2   # outside [2048, 8192]
     with pytest.raises(_lib.ArcqError):
         _lib.check(-1, "demo")
+
+
+def test_round2_entry_points_reject_bad_arguments_without_a_gpu():
+    """The fused decode linears, the contiguous dynamic quantiser, the stream variant of the repacked GEMM and the harness entry
+    points validate before any HIP call (status codes of include/arcq.h: -1 shape, -2 unsupported, -4 NULL)."""
+    L = _lib.lib()
+    P = 4096                                                   # a fake, 16-byte aligned device pointer: never dereferenced on these paths
+    fs = L.arcq_linear_fused_supported
+    assert fs(1, 4, 3584, 3584, 64) == 1 and fs(2, 4, 3584, 512, 64) == 1 and fs(2, 4, 3584, 18944, 64) == 1
+    assert fs(1, 17, 3584, 3584, 64) == 0                      # M > 16
+    assert fs(1, 4, 3584, 1024, 64) == 0                       # the RMSNorm source covers the reference's 2048 .. 8192
+    assert fs(2, 16, 4096, 18944, 64) == 0                     # the fp16 image of 16 x 19008 does not fit LDS
+    assert fs(3, 4, 3584, 3584, 64) == 0                       # unknown source kind
+    # arcq_quantize_x_dyn_slots with reorder_index == NULL (identity order)
+    q = L.arcq_quantize_x_dyn_slots
+    assert q(None, None, None, None, None, None, 0, 4, 3584, 64, 1, None) == -4
+    assert q(P, None, None, None, P, P, 8, 4, 3600, 64, 1, None) == -1 and b"KQ%64" in L.arcq_last_error()
+    assert q(P, None, None, None, P, P, 8, 0, 3584, 64, 1, None) == 0                    # empty input
+    assert q(P, None, None, None, P, P, 8, 4, 3584, 64, 1, None) == -4                    # NULL outputs
+    assert q(P + 2, None, P, P, P, P, 8, 4, 3584, 64, 1, None) == -1 and b"aligned" in L.arcq_last_error()
+    # fused linears
+    lin = L.arcq_linear_rmsnorm_repacked
+    assert lin(P, P, 1e-6, P, P, P, P, 17, 3584, 3584, 64, 1, 1.0, None, None, None, 0, None) == -2
+    assert lin(P, P, 1e-6, P, P, P, P, 4, 3584, 3584, 64, 1, 1.0, None, None, None, 7, None) == -1      # out_dtype
+    assert lin(P, None, 1e-6, P, P, P, P, 4, 3584, 3584, 64, 1, 1.0, None, None, None, 0, None) == -4   # norm weight
+    silu = L.arcq_linear_rmsnorm_silu_repacked
+    assert silu(P, P, 1e-6, P, P, P, P, P, 4, 3586, 3584, 64, 1, 1.0, None, None, None, None) == -1 and b"N % 4" in L.arcq_last_error()
+    assert silu(P, P, 1e-6, P, P, P, P, P, 4, 3584, 3584, 64, 1, 1.0, None, None, P + 2, None) == -1    # act_scatter_index alignment
+    assert L.arcq_linear_dynamic_repacked(P, P, P, P, P, None, None, 0, 4, 3584, 3584, 100, 1, 1.0, None, None, 0, None) == -1
+    for fn in (L.arcq_gemm_nvfp4_repacked, L.arcq_gemm_nvfp4_repacked_stream):
+        assert fn(P, P, P, P, P, 17, 4096, 4160, 1.0, None, None, None, 0, None) == -2
+    # harness (include/arcq_harness.h)
+    assert L.arcq_harness_attn_decode_window(P, P, P, P, P, 4, 28, 1152, 10, 11, None) == -1             # first > pos
+    assert L.arcq_harness_attn_decode(P, P, P, P, P, 4, 28, 1152, 1152, None) == -1                       # pos >= Tmax
+    assert L.arcq_harness_rmsnorm(P, 3584, P, P, 4, 3587, 1e-6, None) == -1
+    assert L.arcq_harness_rmsnorm(P, 3584, P, P, 0, 3584, 1e-6, None) == 0
