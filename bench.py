@@ -394,10 +394,12 @@ def strong_scaling(S, rank, world, device, dist, iters=20):
     def row_gemm_only():
         agemm.matmul(a_sh, rp.W, sfa_sh, rp.SFW, p["alpha"], out=part)
 
+    # FIXED launch counts, identical on every rank: two of the four steps hold collectives, and time_events_steady's warm-up and
+    # timed counts depend on the rank's own measured time -- ranks would issue different numbers of collectives and hang
     for name, fn in (("column_parallel_allgather", col_step), ("column_parallel_gemm_only", col_gemm_only),
                      ("row_parallel_reduce_scatter_allgather", row_step), ("row_parallel_gemm_only", row_gemm_only)):
         dist.barrier()
-        us = time_events_steady(fn, iters, 30.0)
+        us = time_events(fn, 5 * iters, 300)                   # >= 300 launches first: past the clock ramp after idle
         t = torch.tensor([us], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         out[name] = {"us": round(float(t.item()), 1), "TFLOPs_total": round(flops / float(t.item()) / 1e6, 1)}
@@ -418,6 +420,9 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default, the contract's mode): every rank its own 4096 output columns, no data-path collective; strong: ONE "
                          "4096^2 ARC-GEMM split over the ranks (column-parallel shards + RCCL all-gather of the bf16 output) as the timed step")
+    ap.add_argument("--strong-extra", action="store_true",
+                    help="with --gpus N > 1: also time ONE 4096^2 and ONE 8192^2 ARC-GEMM split over the ranks both tensor-parallel ways, "
+                         "with their RCCL exchange (extra.strong_scaling)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     args = ap.parse_args()
@@ -470,7 +475,12 @@ def main():
             dist.all_gather_into_tensor(gathered, y_sh)
 
     if args.prewarm_ms > 0:                       # untimed: bring the clocks to their sustained state (see time_events_steady)
-        time_events_steady(step, 5, args.prewarm_ms)
+        if strong:                                # the step holds a collective: the SAME launch count on every rank (an adaptive count hangs)
+            for _ in range(300):
+                step()
+            torch.cuda.synchronize()
+        else:
+            time_events_steady(step, 5, args.prewarm_ms)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -537,12 +547,17 @@ def main():
             result["cpu_baseline"] = cpu_baseline()
         if not args.no_extra:
             result["extra"] = bench_extra(args, device, rank)
-    elif world > 1 and not args.no_extra:
-        # strong scaling of ONE fixed GEMM over the ranks, with the collective a real layer pays (reported beside, never part of a weak `value`)
+    elif world > 1 and args.strong_extra and not args.no_extra:
+        # strong scaling of ONE fixed GEMM over the ranks, with the collective a real layer pays (reported beside, never part of a weak
+        # `value`).  OPT-IN (--strong-extra): these RCCL paths cannot be rehearsed on the one-GPU boxes this repository is developed on,
+        # and a fault in a secondary measurement must not cost the run its one JSON line.
         strong_x = {}
         if backend == "nccl":                                  # reduce-scatter / bf16 collectives: RCCL only (the gloo rehearsal skips them)
             for S in (4096, 8192):
-                strong_x[f"gemm_{S}"] = strong_scaling(S, rank, world, device, dist)
+                try:
+                    strong_x[f"gemm_{S}"] = strong_scaling(S, rank, world, device, dist)
+                except Exception as e:                          # symmetric failures (shapes, memory) keep the headline line alive
+                    strong_x[f"gemm_{S}"] = {"error": repr(e)[:200]}
         if rank == 0:
             result["extra"] = {"strong_scaling": strong_x}
     if rank == 0:
