@@ -13,9 +13,9 @@ e = d["extra"]
 names = {"decode_gemm_M1_N4096_KQ4096": "config[1] M=1 N=4096 KQ=4096", "decode_gemm_M4_N4096_KQ4096": "M=4 N=4096 KQ=4096",
          "decode_gemm_M16_N4096_KQ4096": "M=16 N=4096 KQ=4096", "decode_gemm_M1_N14336_KQ4096": "config[2] gate/up M=1 N=14336 KQ=4096",
          "decode_gemm_M1_N4096_KQ14336": "config[2] down M=1 N=4096 KQ=14336", "decode_gemm_M1_N1024_KQ4096": "config[2] k/v M=1 N=1024 KQ=4096",
-         "decode_gemm_M4_N3584_KQ3584": "config[3] o M=4 N=3584 KQ=3584", "decode_gemm_M4_N10752_KQ3584": "config[3] q|k|v M=4 N=10752 KQ=3584",
-         "decode_gemm_M4_N37888_KQ3584": "config[3] gate|up M=4 N=37888 KQ=3584", "decode_gemm_M4_N3584_KQ18944": "config[3] down M=4 N=3584 KQ=18944",
-         "decode_gemm_M4_N1280_KQ8192": "config[4] rank q|k|v M=4 N=1280 KQ=8192", "decode_gemm_M4_N7168_KQ8192": "config[4] rank gate|up M=4 N=7168 KQ=8192",
+         "decode_gemm_M4_N3584_KQ3584": "config[3] o M=4 N=3584 KQ=3584", "decode_gemm_M4_N10752_KQ3584": "config[3] q\\|k\\|v M=4 N=10752 KQ=3584",
+         "decode_gemm_M4_N37888_KQ3584": "config[3] gate\\|up M=4 N=37888 KQ=3584", "decode_gemm_M4_N3584_KQ18944": "config[3] down M=4 N=3584 KQ=18944",
+         "decode_gemm_M4_N1280_KQ8192": "config[4] rank q\\|k\\|v M=4 N=1280 KQ=8192", "decode_gemm_M4_N7168_KQ8192": "config[4] rank gate\\|up M=4 N=7168 KQ=8192",
          "decode_gemm_M4_N8192_KQ1024": "config[4] rank o M=4 N=8192 K slice 1088", "decode_gemm_M4_N8192_KQ3584": "config[4] rank down M=4 N=8192 K slice 3648"}
 t = "| shape (KE = 64) | reference layout µs | repacked µs | TB/s (best) | of 8 TB/s | fp16 library µs | speed-up |\n|---|---|---|---|---|---|---|\n"
 for k, n in names.items():
