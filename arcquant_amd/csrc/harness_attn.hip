@@ -5,13 +5,15 @@
 // (1.2 TB/s; tools/sdpa_decode_probe.py) -- 41 % of the measured Qwen2.5-7B full-cache decode step.  This is the streaming
 // form of that one call (flash-decoding): HBM-bound, bytes = 2 * B * H * T * 128 * 2.
 //
-//   attn_decode_partial: grid (B * H, S): workgroup (b, h, s) streams K then V of its slice of the sequence with fully
-//       coalesced 16-byte loads (a wave reads four 256-byte rows per instruction), scores and probabilities through LDS,
-//       fp32 throughout; the slice that holds the NEW token takes k/v from the fused q|k|v projection output and appends them
-//       to the cache on the way (replaces the harness's strided copy launch); leaves (max, sum, 128 accumulators) per slice
-//   attn_decode_combine: grid (B * H): merges the S slices (log-sum-exp) and writes bf16 [B, H * 128]
+//   attn_decode_fused (default): ONE launch, grid (B * H) x 512 threads: every wave streams a contiguous range of positions with an
+//       online softmax, K and V rows of a 16-position block requested together and double-buffered; the waves' records merge in LDS;
+//       the new token's k / v come from the fused q|k|v projection output and are appended to the cache on the way (replaces the
+//       harness's strided copy launch).  fp32 throughout.
+//   attn_decode_partial + attn_decode_combine (ARCQ_HARNESS_ATTN_SLICED=1, the A-B alternative it was measured against: full-cache
+//       1707 vs 1714 tok/s, current-token 2070 vs 2092): grid (B * H, S) slices with a two-pass softmax through LDS, then a merge launch
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "arcq_device.hpp"
 #include "arcq_internal.hpp"
@@ -186,6 +188,127 @@ __global__ __launch_bounds__(kAttnD) void attn_decode_combine(AttnParams p) {
   p.out[(size_t)b * p.H * kAttnD + (size_t)h * kAttnD + d] = (uint16_t)f32_to_bf16_bits(a / L);
 }
 
+// ONE launch, no scratch: a 512-thread workgroup per (batch, head); its 8 waves each stream a contiguous range of positions with an
+// online softmax (running max / sum / accumulator, K and V of a 16-position block requested together, the next block's rows in
+// flight while this one is reduced), then merge their 8 (max, sum, accumulator) records through LDS.  112 workgroups do not fill the
+// 256 CUs, but 8 waves x 16 outstanding 1-KB loads per CU keep ~60 MB in ~12 us within reach, and the slice kernel's second launch,
+// its scratch round trip and its 37 % imbalance (560 slices on 256 CUs) disappear.
+constexpr int kAttnFusedWaves = 8;
+__global__ __launch_bounds__(kAttnFusedWaves * 64) void attn_decode_fused(AttnParams p) {
+  __shared__ float rec[kAttnFusedWaves][kAttnD + 2];
+  const int bh = blockIdx.x;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane >> 4, c = lane & 15;                  // row within a 4-row wave load, 16-byte column chunk
+  const int T = p.pos + 1;                                 // positions attended: [first, pos]
+  const int per = ((T - p.first + kAttnFusedWaves - 1) / kAttnFusedWaves + 3) & ~3;      // positions per wave, whole 4-row loads
+  const int t0 = p.first + wave * per, t1 = min(T, t0 + per);
+  const size_t hidden = (size_t)p.H * kAttnD;
+  const uint16_t* qrow = p.qkv + (size_t)b * 3 * hidden + (size_t)h * kAttnD;
+  uint16_t* K = p.kcache + ((size_t)bh * p.Tmax) * kAttnD;
+  uint16_t* V = p.vcache + ((size_t)bh * p.Tmax) * kAttnD;
+  if (tid < 2 * kAttnD / 8) {                              // the new token's k / v: append to the cache (read below from the projection output)
+    const int which = tid >> 4, cc = tid & 15;
+    const uint4 d = *reinterpret_cast<const uint4*>(qrow + (1 + which) * hidden + cc * 8);
+    *reinterpret_cast<uint4*>((which ? V : K) + (size_t)p.pos * kAttnD + cc * 8) = d;
+  }
+  float q8[8];
+  {
+    const uint4 d = *reinterpret_cast<const uint4*>(qrow + c * 8);
+    const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      q8[2 * j] = bf16_bits_to_f32(w[j] & 0xffffu) * p.scale;
+      q8[2 * j + 1] = bf16_bits_to_f32(w[j] >> 16) * p.scale;
+    }
+  }
+  auto row_ptr = [&](const uint16_t* base, int which, int t) -> const uint16_t* {
+    return t == p.pos ? qrow + which * hidden : base + (size_t)t * kAttnD;
+  };
+  auto load_block = [&](int tb, uint4 (&kk)[4], uint4 (&vv)[4]) __attribute__((always_inline)) {
+    const int last = max(t1 - 1, p.first);                   // (an idle wave clamps to a valid row and masks everything)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) kk[u] = *reinterpret_cast<const uint4*>(row_ptr(K, 1, min(tb + u * 4 + r, last)) + c * 8);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) vv[u] = *reinterpret_cast<const uint4*>(row_ptr(V, 2, min(tb + u * 4 + r, last)) + c * 8);
+  };
+  float m = -3.0e38f, l = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  uint4 k0[4], v0[4], k1[4], v1[4];
+  auto consume = [&](int tb, const uint4 (&kk)[4], const uint4 (&vv)[4]) __attribute__((always_inline)) {
+    float d[4], mb = -3.0e38f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t w[4] = {kk[u].x, kk[u].y, kk[u].z, kk[u].w};
+      float x = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x += q8[2 * j] * bf16_bits_to_f32(w[j] & 0xffffu) + q8[2 * j + 1] * bf16_bits_to_f32(w[j] >> 16);
+#pragma unroll
+      for (int sh = 8; sh > 0; sh >>= 1) x += __shfl_xor(x, sh, 64);
+      d[u] = tb + u * 4 + r < t1 ? x : -3.0e38f;
+      mb = fmaxf(mb, d[u]);
+    }
+    mb = fmaxf(mb, __shfl_xor(mb, 16, 64));                  // over the four row groups: the block's maximum, wave-uniform
+    mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+    const float mn = fmaxf(m, mb), a = __expf(m - mn);
+    l *= a;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] *= a;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float pt = tb + u * 4 + r < t1 ? __expf(d[u] - mn) : 0.f;
+      l += pt;                                               // (this lane's row group; the groups are added at the end)
+      const uint32_t w[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[2 * j] += pt * bf16_bits_to_f32(w[j] & 0xffffu);
+        acc[2 * j + 1] += pt * bf16_bits_to_f32(w[j] >> 16);
+      }
+    }
+    m = mn;
+  };
+  if (t0 < t1) {
+    load_block(t0, k0, v0);
+    for (int tb = t0; tb < t1; tb += 32) {                   // two 16-position blocks per trip: the other buffer's loads stay in flight
+      if (tb + 16 < t1) load_block(tb + 16, k1, v1);         // (a third buffer measured slower: 1700 vs 1714 tok/s full-cache)
+      consume(tb, k0, v0);
+      if (tb + 16 < t1) {
+        if (tb + 32 < t1) load_block(tb + 32, k0, v0);
+        consume(tb + 16, k1, v1);
+      }
+    }
+  }
+  // the four row groups of a wave hold the same columns: add them; then the wave's record
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    acc[j] += __shfl_xor(acc[j], 16, 64);
+    acc[j] += __shfl_xor(acc[j], 32, 64);
+  }
+  if (r == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rec[wave][2 + c * 8 + j] = acc[j];
+    if (c == 0) {
+      rec[wave][0] = m;
+      rec[wave][1] = l;
+    }
+  }
+  __syncthreads();
+  if (tid < kAttnD) {                                        // merge of the waves (idle ones carry m = -3e38, l = 0)
+    float M = -3.0e38f;
+#pragma unroll
+    for (int w = 0; w < kAttnFusedWaves; ++w) M = fmaxf(M, rec[w][0]);
+    float L = 0.f, a = 0.f;
+#pragma unroll
+    for (int w = 0; w < kAttnFusedWaves; ++w) {
+      const float f = __expf(rec[w][0] - M);
+      L += rec[w][1] * f;
+      a += rec[w][2 + tid] * f;
+    }
+    p.out[(size_t)b * hidden + (size_t)h * kAttnD + tid] = (uint16_t)f32_to_bf16_bits(a / L);
+  }
+}
+
 // The model's final RMSNorm (not an ARC operator: the reference uses the stock module there) as ONE launch for the harness: torch's
 // F.rms_norm is ~15 small kernels on this stack, ~40 us of a 2 ms decode step with its index arithmetic.  One workgroup per row,
 // fp32 throughout: out = bf16(float(x) * rsqrt(mean(x^2) + eps) * float(w)).
@@ -265,6 +388,13 @@ extern "C" int arcq_harness_attn_decode_window(const void* qkv, void* kcache, vo
   p.S = S; p.chunk = chunk;
   p.scale = 0.08838834764831845f;                           // 128^-0.5
   const int live = (T + chunk - 1) / chunk;
+  static const int sliced = getenv("ARCQ_HARNESS_ATTN_SLICED") ? atoi(getenv("ARCQ_HARNESS_ATTN_SLICED")) : 0;   // A-B: the two-launch slice kernels
+  if (!sliced) {
+    hipLaunchKernelGGL(attn_decode_fused, dim3((unsigned)(B * H)), dim3(kAttnFusedWaves * 64), 0, (hipStream_t)stream, p);
+    hipError_t e1 = hipGetLastError();
+    if (e1 != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "%s: launch failed: %s", who, hipGetErrorString(e1));
+    return ARCQ_OK;
+  }
   hipLaunchKernelGGL(attn_decode_partial, dim3((unsigned)(B * H), (unsigned)live), dim3(kAttnThreads), 0, (hipStream_t)stream, p);
   if (live > 1) hipLaunchKernelGGL(attn_decode_combine, dim3((unsigned)(B * H)), dim3(kAttnD), 0, (hipStream_t)stream, p);
   hipError_t e = hipGetLastError();

@@ -22,11 +22,12 @@ int64_t arcq_harness_attn_workspace_bytes(int64_t B, int64_t H, int64_t Tmax);
 
 /* One decode step of attention, head dimension 128: qkv = bf16 [B, 3*H*128] (q | k | v of the ONE new token per sequence, the
  * fused projection's output), kcache / vcache = bf16 [B, H, Tmax, 128].  Appends k / v at position `pos`, then
- * out[b, h*128 + d] = softmax(q k^T / sqrt(128)) v over positions [0, pos] (fp32 math, bf16 result).  Two launches on `stream`. */
+ * out[b, h*128 + d] = softmax(q k^T / sqrt(128)) v over positions [0, pos] (fp32 math, bf16 result).  One launch on `stream`; `workspace` is
+ * only used by the sliced two-launch variant (environment ARCQ_HARNESS_ATTN_SLICED=1). */
 int arcq_harness_attn_decode(const void *qkv, void *kcache, void *vcache, void *out, void *workspace, int64_t B, int64_t H,
                              int64_t Tmax, int64_t pos, void *stream);
 /* The same over positions [first, pos] only (0 <= first <= pos); first == pos is the attention benchmarks/modeling_arc.py:169-198
- * times in a decode step (each sequence attends over the tokens of the current call).  One launch when the window is one slice. */
+ * times in a decode step (each sequence attends over the tokens of the current call). */
 int arcq_harness_attn_decode_window(const void *qkv, void *kcache, void *vcache, void *out, void *workspace, int64_t B, int64_t H,
                                     int64_t Tmax, int64_t pos, int64_t first, void *stream);
 
