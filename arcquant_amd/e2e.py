@@ -408,9 +408,131 @@ def bench_protocol(name="qwen2.5-7b", batch=4, prefill=1024, decode_steps=128, d
             "peak_memory_gb": round(max(p_mem, d_mem, e_mem) / 2 ** 30, 3)}
 
 
+# ---- BASELINE config[4]: one Llama-3-70B-shape decoder layer per rank of a tensor-parallel group -------------------------------------
+LLAMA3_70B = dict(hidden=8192, heads=64, kv_heads=8, head_dim=128, inter=28672, layers=80)
+
+
+def build_tp_layer(rank, world, device, batch, max_len, cfg=None, KE=64, seed=0, ops=None, repack=True, group=None):
+    """This rank's shard of ONE decoder layer with random weights (tp.TPDecoderLayer; the shards are drawn directly, seed + rank,
+    each with its own per-tensor weight scale), identity reorder indices, ``select_num`` = KE for every linear (per shard for the
+    row-parallel ones: hand-off B)."""
+    from . import tp
+    cfg = dict(LLAMA3_70B if cfg is None else cfg)
+    h, hd = cfg["hidden"], cfg["head_dim"]
+    hq, hk, it = cfg["heads"] // world * hd, cfg["kv_heads"] // world * hd, cfg["inter"] // world
+    g = torch.Generator(device=device).manual_seed(seed * 1000 + rank)
+
+    def rnd(n, k):
+        return (torch.randn(n, k, generator=g, device=device, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+
+    shards = dict(wqkv=rnd(hq + 2 * hk, h), wo=rnd(h, hq), wgu=rnd(2 * it, h), wd=rnd(h, it))
+    ones = torch.ones(h, dtype=torch.bfloat16, device=device)
+    idx_h = torch.arange(h, dtype=torch.int16, device=device)
+    idx_o = torch.arange(hq, dtype=torch.int16, device=device)
+    idx_d = torch.arange(it, dtype=torch.int16, device=device)
+    return tp.TPDecoderLayer.build(shards, ones, ones.clone(), idx_h, idx_o, idx_d, KE, KE, KE, rank, world, cfg["heads"], cfg["kv_heads"], hd,
+                                   batch, max_len, eps=1e-5, group=group, ops=ops, repack=repack)
+
+
+def bench_tp_layer(rank, world, device, batch=4, pos=1040, steps=50, warmup=10, cfg=None):
+    """Decode step of ONE tensor-parallel decoder layer (Llama-3-70B shape by default): per-layer time with its four collectives
+    (2 x all-reduce(MAX) of 4 B, 2 x all-reduce(SUM) of the fp32 [batch, hidden] partial), the same step with the collectives
+    skipped (what the rank's four launches + attention cost alone), max over ranks.  Launches are issued eagerly."""
+    import torch.distributed as dist
+    from . import tp
+    cfg = dict(LLAMA3_70B if cfg is None else cfg)
+    with torch.no_grad():
+        layer = build_tp_layer(rank, world, device, batch, pos + 8, cfg)
+        h = (torch.randn(batch, cfg["hidden"], device=device, generator=torch.Generator(device=device).manual_seed(7)) * 0.5).to(torch.bfloat16)
+
+        def timed(fn):
+            for _ in range(warmup):
+                fn()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            t = torch.tensor([e0.elapsed_time(e1) * 1e3 / steps], dtype=torch.float64, device=device)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        with_coll = timed(lambda: layer.forward(h, pos))
+        out = layer.forward(h, pos)
+        # the same launches without the exchange: the linears think they are alone (world = 1); results are then partial sums
+        for m in (layer.o, layer.down):
+            m.world = 1
+        grp, layer.group = layer.group, None
+        saved = tp.handoff_local_scale
+        tp.handoff_local_scale = lambda y_local=None, group=None, word=None: (tp.absmax_word(y_local) if word is None else word)
+        try:
+            no_coll = timed(lambda: layer.forward(h, pos))
+        finally:
+            tp.handoff_local_scale = saved
+            layer.group = grp
+            for m in (layer.o, layer.down):
+                m.world = world
+        same = True
+        if world > 1:                                          # the replicated hidden state must be bit-identical on every rank
+            ref = out.clone()
+            dist.broadcast(ref, src=0)
+            flag = torch.tensor([int(torch.equal(ref, out))], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            same = bool(flag.item())
+    wbytes = sum(m.W.numel() * 9 // 8 for m in (layer.qkv, layer.o, layer.gateup, layer.down))
+    return {"model": "llama-3-70b-shape decoder layer", "tp": world, "batch": batch, "attn_window": pos, "launches": "eager",
+            "layer_us_with_collectives": round(with_coll, 1), "layer_us_without_collectives": round(no_coll, 1),
+            "weight_bytes_per_rank": int(wbytes), "collective_bytes": tp.TPDecoderLayer.collective_bytes_per_layer(batch, cfg["hidden"], world),
+            "output_identical_on_all_ranks": same,
+            "decode_tok_per_s_80_layers_est": round(batch / (with_coll * cfg["layers"]) * 1e6, 1)}
+
+
+def _tp_main(argv):
+    """python -m arcquant_amd.e2e --tp N [--steps K]: one rank per GPU (self-launched, or under torch.distributed.run).
+    Rehearsal on a one-GPU box: ARCQ_BENCH_ONE_DEVICE=1 ARCQ_BENCH_BACKEND=gloo."""
+    import json
+    import os
+    import sys
+    from . import launch
+    n = int(argv[argv.index("--tp") + 1])
+    steps = int(argv[argv.index("--steps") + 1]) if "--steps" in argv else 50
+    if n > 1 and not launch.launched():
+        sys.exit(launch.launch_ranks(n, [sys.executable, "-m", "arcquant_amd.e2e"] + list(argv)))
+    world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    one_device = os.environ.get("ARCQ_BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("ARCQ_BENCH_BACKEND", "nccl")
+    dev_index = 0 if one_device else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+    cfg = None
+    if "--small" in argv:                                      # a quick functional pass (tests): 1/8 of the 70B layer in every dimension
+        cfg = dict(hidden=2048, heads=16, kv_heads=2 * max(1, world), head_dim=128, inter=7168 // 8 * 8, layers=80)
+    res = bench_tp_layer(rank, world, device, steps=steps, cfg=cfg)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 if __name__ == "__main__":
     import json
     import sys
+    if "--tp" in sys.argv:
+        _tp_main(sys.argv[1:])
+        sys.exit(0)
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     name = args[0] if args else "qwen2.5-7b"
     if "--protocol" in sys.argv:      # the reference's own benchmark protocol (growing cache, mean +- 1.96 sigma)

@@ -360,12 +360,12 @@ def cpu_baseline():
                       f"{min(t_w):.3f} s; torch {torch.__version__} CPU, {cores} threads"}
 
 
-def strong_scaling(S, rank, world, device, dist, iters=20):
-    """ONE S x S x (S + 64) ARC-GEMM split over `world` ranks, both tensor-parallel ways, with their exchange step:
+def strong_scaling(S, rank, world, device, dist, iters=20, two_shot=True):
+    """ONE S x S x (S + 64) ARC-GEMM split over `world` ranks, both tensor-parallel ways, with the exchange arcquant_amd/tp.py performs:
       column-parallel: rank r owns output columns [r N/p, (r+1) N/p) (128-row scale tiles stay whole), full activation;
-                       RCCL all-gather of the bf16 [M, N/p] blocks (what a q/k/v/gate/up layer pays when its output is needed whole);
+                       all-gather of the bf16 [M, N/p] blocks (what a q/k/v/gate/up layer pays when its output is needed whole);
       row-parallel:    rank r owns a 64-aligned slice of the augmented K axis of BOTH operands; bf16 partial [M, N] ->
-                       reduce-scatter + all-gather (two-shot all-reduce: the o_proj / down_proj exchange).
+                       tp.all_reduce_sum (two-shot: reduce-scatter + all-gather over RCCL; one all-reduce on the gloo rehearsal).
     Times are the max over ranks (HIP events around GEMM + collective on the current stream)."""
     from arcquant_amd import agemm, tp
     M = N = KQ = S
@@ -391,14 +391,10 @@ def strong_scaling(S, rank, world, device, dist, iters=20):
     rp = tp.RowParallelARCLinear(p["qw"], p["sfw"], p["sw"], rank, world)
     a_sh, sfa_sh = rp.shard_activation(p["qx"], p["sfx"])
     part = torch.empty((M, N), dtype=torch.bfloat16, device=device)
-    rows = M // world
-    scat = torch.empty((rows, N), dtype=torch.bfloat16, device=device)
-    full = torch.empty((M, N), dtype=torch.bfloat16, device=device)
 
     def row_step():
         agemm.matmul(a_sh, rp.W, sfa_sh, rp.SFW, p["alpha"], out=part)
-        dist.reduce_scatter_tensor(scat, part)
-        dist.all_gather_into_tensor(full, scat)
+        tp.all_reduce_sum(part, two_shot=two_shot)
 
     def row_gemm_only():
         agemm.matmul(a_sh, rp.W, sfa_sh, rp.SFW, p["alpha"], out=part)
@@ -406,14 +402,52 @@ def strong_scaling(S, rank, world, device, dist, iters=20):
     # FIXED launch counts, identical on every rank: two of the four steps hold collectives, and time_events_steady's warm-up and
     # timed counts depend on the rank's own measured time -- ranks would issue different numbers of collectives and hang
     for name, fn in (("column_parallel_allgather", col_step), ("column_parallel_gemm_only", col_gemm_only),
-                     ("row_parallel_reduce_scatter_allgather", row_step), ("row_parallel_gemm_only", row_gemm_only)):
+                     ("row_parallel_bf16_two_shot_allreduce" if two_shot else "row_parallel_bf16_allreduce", row_step),
+                     ("row_parallel_gemm_only", row_gemm_only)):
         dist.barrier()
         us = time_events(fn, 5 * iters, 300)                   # >= 300 launches first: past the clock ramp after idle
         t = torch.tensor([us], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        out[name] = {"us": round(float(t.item()), 1), "TFLOPs_total": round(flops / float(t.item()) / 1e6, 1)}
+        out[name] = {"us": round(float(t.item()), 1), "TFLOPs_total": round(flops / float(t.item()) / 1e6, 1),
+                     "frac_of_fp4_peak_total": round(flops / float(t.item()) / 1e6 / (world * PEAK_FP4_TFLOPS), 4)}
+    rows = M // world
     out["bytes_exchanged_per_rank"] = {"column_parallel": int((world - 1) * M * wmax * 2), "row_parallel": int(2 * (world - 1) * rows * N * 2)}
     return out
+
+
+def _extras_child(conn, backend, one_device):
+    """Runs in a process of its own, started by its rank BEFORE that rank touched the GPU: waits for the rendezvous port, then times
+    the strong-scaling splits over a process group of its own and sends the result back.  A hang or an RCCL abort in here costs
+    the rank's JSON line nothing: the parent waits with a timeout and reports the failure as a string."""
+    try:
+        msg = conn.recv()
+        if not msg:
+            return
+        os.environ["MASTER_PORT"] = str(msg["port"])
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch.distributed as dist
+        rank, world, local_rank = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+        dev_index = 0 if one_device else local_rank
+        torch.cuda.set_device(dev_index)
+        device = torch.device("cuda", dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+        out = {}
+        for S in msg["sizes"]:
+            try:
+                out[f"gemm_{S}"] = strong_scaling(S, rank, world, device, dist, two_shot=(backend == "nccl"))
+            except Exception as e:                               # symmetric failures (shapes, memory) keep the other size alive
+                out[f"gemm_{S}"] = {"error": repr(e)[:200]}
+        conn.send(out)
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:
+        try:
+            conn.send({"error": repr(e)[:300]})
+        except Exception:
+            pass
 
 
 def main():
@@ -429,25 +463,38 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default, the contract's mode): every rank its own 4096 output columns, no data-path collective; strong: ONE "
                          "4096^2 ARC-GEMM split over the ranks (column-parallel shards + RCCL all-gather of the bf16 output) as the timed step")
-    ap.add_argument("--strong-extra", action="store_true",
-                    help="with --gpus N > 1: also time ONE 4096^2 and ONE 8192^2 ARC-GEMM split over the ranks both tensor-parallel ways, "
-                         "with their RCCL exchange (extra.strong_scaling)")
+    ap.add_argument("--no-strong-extra", action="store_true",
+                    help="with --gpus N > 1: do NOT time the strong-scaling splits (ONE 4096^2 and ONE 8192^2 ARC-GEMM over the ranks, both "
+                         "tensor-parallel ways with their exchange; extra.strong_scaling).  They run in a helper process per rank, so a "
+                         "failing collective costs the JSON line nothing")
+    ap.add_argument("--strong-extra", action="store_true", help=argparse.SUPPRESS)      # round-2 spelling: now the default
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     args = ap.parse_args()
 
+    from arcquant_amd import launch
+    if args.gpus > 1 and not launch.launched():
+        # `python bench.py --gpus N` as the driver runs it: start the N ranks ourselves.  This parent makes no GPU call.
+        sys.exit(launch.launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py: for --gpus N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ...`")
-        args.gpus = world
+    args.gpus = world
     # Rehearsal switches (not used by the driver): ARCQ_BENCH_ONE_DEVICE=1 maps every rank to cuda:0 and
     # ARCQ_BENCH_BACKEND=gloo replaces RCCL, so the N > 1 code path can be exercised on a one-GPU box.
     one_device = os.environ.get("ARCQ_BENCH_ONE_DEVICE") == "1"
     backend = os.environ.get("ARCQ_BENCH_BACKEND", "nccl")
     dev_index = 0 if one_device else local_rank
+    # the strong-scaling extras run in a helper process of this rank, started NOW -- before this process touches the GPU (an exec
+    # from a GPU-initialised process is refused on the pool) -- and idle until the headline has been measured
+    helper = helper_conn = None
+    if world > 1 and not args.no_extra and not args.no_strong_extra:
+        import multiprocessing as mp
+        ctx = mp.get_context("spawn")
+        helper_conn, child_conn = ctx.Pipe()
+        helper = ctx.Process(target=_extras_child, args=(child_conn, backend, one_device), daemon=True)
+        helper.start()
+        child_conn.close()
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
@@ -556,18 +603,28 @@ def main():
             result["cpu_baseline"] = cpu_baseline()
         if not args.no_extra:
             result["extra"] = bench_extra(args, device, rank)
-    elif world > 1 and args.strong_extra and not args.no_extra:
+    elif helper is not None:
         # strong scaling of ONE fixed GEMM over the ranks, with the collective a real layer pays (reported beside, never part of a weak
-        # `value`).  OPT-IN (--strong-extra): these RCCL paths cannot be rehearsed on the one-GPU boxes this repository is developed on,
-        # and a fault in a secondary measurement must not cost the run its one JSON line.
+        # `value`), in the helper processes: own process group on a fresh port, bounded wait.  A hang, an RCCL abort or a crash in
+        # there becomes an "error" string; this rank's JSON line does not depend on it.
         strong_x = {}
-        if backend == "nccl":                                  # reduce-scatter / bf16 collectives: RCCL only (the gloo rehearsal skips them)
-            for S in (4096, 8192):
-                try:
-                    strong_x[f"gemm_{S}"] = strong_scaling(S, rank, world, device, dist)
-                except Exception as e:                          # symmetric failures (shapes, memory) keep the headline line alive
-                    strong_x[f"gemm_{S}"] = {"error": repr(e)[:200]}
+        try:
+            port = torch.tensor([launch.free_port() if rank == 0 else 0], dtype=torch.int64, device=device)
+            dist.broadcast(port, src=0)
+            helper_conn.send({"port": int(port.item()), "sizes": [4096, 8192]})
+            if helper_conn.poll(float(os.environ.get("ARCQ_BENCH_EXTRA_TIMEOUT_S", "240"))):
+                strong_x = helper_conn.recv()
+            else:
+                strong_x = {"error": "no answer from the strong-scaling helper within its time limit"}
+        except Exception as e:
+            strong_x = {"error": repr(e)[:200]}
+        helper.join(timeout=20)
+        if helper.is_alive():
+            helper.kill()                                       # our own child, by handle
         if rank == 0:
+            strong_x["note"] = ("ONE S x S x (S+64) ARC-GEMM split over the ranks: column-parallel + all-gather of the bf16 output; row-parallel "
+                                "(64-aligned slices of the augmented K axis) + tp.all_reduce_sum of the bf16 partial (two-shot: reduce-scatter "
+                                "+ all-gather); us = max over ranks, HIP events around GEMM + collective")
             result["extra"] = {"strong_scaling": strong_x}
     if rank == 0:
         print(json.dumps(result))

@@ -16,18 +16,33 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _gpu_count():
+    # torch.cuda.device_count() does not initialise the GPU on this image (torch.cuda.is_available() does): a process that has
+    # initialised it may not exec another program on the MI355X pool, and the fork server below must start before that
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:  # pragma: no cover
+        return 0
+
+
+# Tests that must START PROGRAMS on the GPU box (tests/test_bench_launch_gpu.py: `python bench.py --gpus 2`) do it through a fork
+# server that is started here, while this process is still GPU-free: its children never inherit a GPU-initialised state.
+FORKSERVER = None
+if _gpu_count() > 0:
+    import multiprocessing as _mp
+    from multiprocessing import forkserver as _fs
+    FORKSERVER = _mp.get_context("forkserver")
+    _fs.ensure_running()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
 def pytest_collection_modifyitems(config, items):
     # GPU tests are skipped (not failed) when no device is present, e.g. a bare `pytest tests/`.
-    try:
-        import torch
-        have_gpu = torch.cuda.is_available()
-    except Exception:  # pragma: no cover
-        have_gpu = False
-    if have_gpu:
+    if _gpu_count() > 0:
         return
     skip = pytest.mark.skip(reason="no GPU in this container")
     for item in items:
