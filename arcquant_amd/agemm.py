@@ -298,7 +298,8 @@ def repack_w(QW: torch.Tensor, SFW: torch.Tensor):
 
 @functools.lru_cache(maxsize=None)
 def repacked_supported(M: int, N: int, K: int) -> bool:
-    """Whether ``matmul_repacked`` can run this shape (M <= 16 and the fp16 image of the activations fits LDS)."""
+    """Whether ``matmul_repacked`` can run this shape: M <= 16 and the fp16 image of the activations fits LDS, or 16 < M <= 64 and
+    the packed activations fit LDS (decode batches: the weight is still read once)."""
     return bool(_lib.lib().arcq_gemm_repacked_supported(int(M), int(N), int(K)))
 
 
@@ -522,6 +523,24 @@ def rmsnorm_matmul_repacked(X: torch.Tensor, W: torch.Tensor, eps: float, reorde
     return out
 
 
+_scatter_ok = {}
+
+
+def _check_scatter_index(idx: torch.Tensor, n: int):
+    """``act_scatter_index`` values are store columns of the kernel's epilogue: anything but a permutation of 0 .. n-1 writes out of
+    bounds or leaves columns unwritten.  Checked ONCE per index tensor (one device sync, at registration time in effect), cached by
+    storage address and version counter."""
+    key = (idx.data_ptr(), idx.numel(), idx._version, idx.device.index)
+    if _scatter_ok.get(key):
+        return
+    ok = idx.numel() == n and bool(torch.equal(torch.sort(idx.long()).values, torch.arange(n, device=idx.device)))
+    if not ok:
+        raise RuntimeError(f"agemm: act_scatter_index must be a permutation of 0 .. {n - 1}")
+    if len(_scatter_ok) > 4096:
+        _scatter_ok.clear()
+    _scatter_ok[key] = True
+
+
 def rmsnorm_matmul_repacked_silu(X: torch.Tensor, W: torch.Tensor, eps: float, reorder_index: torch.Tensor, KE: int, RW: torch.Tensor,
                                  RSF: torch.Tensor, scale, N: int, *, scale_host: float = 1.0, variant=None, bias=None,
                                  act_scatter_index=None):
@@ -541,6 +560,9 @@ def rmsnorm_matmul_repacked_silu(X: torch.Tensor, W: torch.Tensor, eps: float, r
         alpha_dev = scale
     else:
         alpha_host *= float(scale)
+    if act_scatter_index is not None:
+        _need(act_scatter_index, torch.int16, "act_scatter_index", 1)
+        _check_scatter_index(act_scatter_index, N // 2)
     act = torch.empty((M, N // 2), dtype=torch.bfloat16, device=X.device)
     slots = torch.empty(((N + 15) // 16,), dtype=torch.int32, device=X.device)
     with _on(X.device):

@@ -62,7 +62,9 @@ int64_t gemm_silu_slots(int64_t M, int64_t N, int64_t K);   // slots the silu-mu
 int64_t gemm_repacked_w_bytes(int64_t N, int64_t K);
 int64_t gemm_repacked_sf_bytes(int64_t N, int64_t K);
 int gemm_repacked_supported(int64_t M, int64_t N, int64_t K);
-int gemm_repacked(const GemmArgs& a, const uint8_t* RW, const uint8_t* RSF, hipStream_t stream);          // gemm_rowblock.hip
+int gemm_repacked(const GemmArgs& a, const uint8_t* RW, const uint8_t* RSF, hipStream_t stream);          // gemm_rowblock.hip (M <= 16), gemm_rowmid.hip above
+int gemm_repacked_mid_supported(int64_t M, int64_t N, int64_t K);                                          // gemm_rowmid.hip: 16 < M <= 64
+int gemm_repacked_mid(const GemmArgs& a, const uint8_t* RW, const uint8_t* RSF, hipStream_t stream);
 int gemm_repacked_stream(const GemmArgs& a, const uint8_t* RW, const uint8_t* RSF, hipStream_t stream);   // gemm_stream.hip (A-B)
 struct FusedArgs {
   int kind;                   // ARCQ_SRC_RMSNORM | ARCQ_SRC_DYNAMIC

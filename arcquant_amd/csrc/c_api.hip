@@ -193,6 +193,9 @@ static int gemm_repacked_entry(bool via_stream, const char* who, const uint8_t* 
   if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(RW) | reinterpret_cast<uintptr_t>(D)) & 15)
     return fail(ARCQ_ERR_SHAPE, "%s: A, RW and D must be 16-byte aligned", who);
   if ((reinterpret_cast<uintptr_t>(SFA) | reinterpret_cast<uintptr_t>(RSF)) & 3) return fail(ARCQ_ERR_SHAPE, "%s: SFA and RSF must be 4-byte aligned", who);
+  // the decode epilogues fetch the four bias / residual values of an output quad with ONE 8-byte load when N % 4 == 0
+  if ((N % 4) == 0 && ((reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) & 7))
+    return fail(ARCQ_ERR_SHAPE, "%s: bias and residual must be 8-byte aligned", who);
   GemmArgs a;
   a.A = A; a.B = nullptr; a.SFA = SFA; a.SFB = nullptr; a.D = D;
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
@@ -259,6 +262,8 @@ int arcq_linear_rmsnorm_repacked(const void* X, const void* Wn, float eps, const
   const int rc = fused_common_checks(who, X, reorder_index, RW, RSF, D, M, N, KQ, KE, variant, out_dtype);
   if (rc != ARCQ_OK) return rc < 0 ? rc : ARCQ_OK;
   if (!Wn || (reinterpret_cast<uintptr_t>(Wn) & 15)) return fail(Wn ? ARCQ_ERR_SHAPE : ARCQ_ERR_NULL, "%s: the norm weight must be a 16-byte aligned pointer", who);
+  if ((N % 4) == 0 && ((reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) & 7))
+    return fail(ARCQ_ERR_SHAPE, "%s: bias and residual must be 8-byte aligned", who);
   FusedArgs f{};
   f.kind = ARCQ_SRC_RMSNORM; f.X = (const uint16_t*)X; f.Wn = (const uint16_t*)Wn; f.eps = eps; f.idx = reorder_index;
   f.RW = RW; f.RSF = RSF; f.D = D; f.M = (int)M; f.N = (int)N; f.KQ = (int)KQ; f.KE = (int)KE; f.variant = variant;
@@ -277,6 +282,7 @@ int arcq_linear_rmsnorm_silu_repacked(const void* X, const void* Wn, float eps, 
   if (!Wn || !absmax_slots) return fail(ARCQ_ERR_NULL, "%s: NULL norm weight / absmax_slots", who);
   if ((reinterpret_cast<uintptr_t>(Wn) & 15) || (reinterpret_cast<uintptr_t>(absmax_slots) & 3)) return fail(ARCQ_ERR_SHAPE, "%s: misaligned norm weight / absmax_slots", who);
   if (reinterpret_cast<uintptr_t>(act_scatter_index) & 3) return fail(ARCQ_ERR_SHAPE, "%s: misaligned act_scatter_index", who);
+  if (reinterpret_cast<uintptr_t>(bias) & 7) return fail(ARCQ_ERR_SHAPE, "%s: bias must be 8-byte aligned", who);
   FusedArgs f{};
   f.act_scatter = act_scatter_index;
   f.kind = ARCQ_SRC_RMSNORM; f.silu_act = 1; f.X = (const uint16_t*)X; f.Wn = (const uint16_t*)Wn; f.eps = eps; f.idx = reorder_index;
@@ -293,6 +299,8 @@ int arcq_linear_dynamic_repacked(const void* X, const int16_t* reorder_index, co
   if (rc != ARCQ_OK) return rc < 0 ? rc : ARCQ_OK;
   if (absmax_slots && (nslots <= 0 || nslots > INT32_MAX || (reinterpret_cast<uintptr_t>(absmax_slots) & 3)))
     return fail(ARCQ_ERR_SHAPE, "%s: absmax_slots given but nslots = %lld, or misaligned", who, (long long)nslots);
+  if ((N % 4) == 0 && ((reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) & 7))
+    return fail(ARCQ_ERR_SHAPE, "%s: bias and residual must be 8-byte aligned", who);
   FusedArgs f{};
   f.kind = ARCQ_SRC_DYNAMIC; f.X = (const uint16_t*)X; f.idx = reorder_index; f.in_slots = absmax_slots; f.n_in_slots = absmax_slots ? (int)nslots : 0;
   f.scale_out = scale_out; f.RW = RW; f.RSF = RSF; f.D = D; f.M = (int)M; f.N = (int)N; f.KQ = (int)KQ; f.KE = (int)KE; f.variant = variant;

@@ -232,15 +232,18 @@ static int rowblock_lds_bytes(int M, int64_t K, int slices, int* a_stride) {
   return M * stride > red ? M * stride : red;
 }
 
-// 1 = this shape can run on the repacked path (M <= 16 and the fp16 activation image fits LDS)
+// 1 = this shape can run on the repacked path: M <= 16 and the fp16 activation image fits LDS (this file), or 16 < M <= 64 and
+// the PACKED activations fit LDS (gemm_rowmid.hip)
 int gemm_repacked_supported(int64_t M, int64_t N, int64_t K) {
-  if (M < 1 || M > 16 || N < 1 || K < 64 || (K % 64)) return 0;
+  if (M > 16) return gemm_repacked_mid_supported(M, N, K);
+  if (M < 1 || N < 1 || K < 64 || (K % 64)) return 0;
   int stride;
   return rowblock_lds_bytes((int)M, K, 8, &stride) <= 160 * 1024 ? 1 : 0;
 }
 
 int gemm_repacked(const GemmArgs& a, const uint8_t* RW, const uint8_t* RSF, hipStream_t stream) {
   static const int use_stream = getenv("ARCQ_REPACKED_STREAM") ? atoi(getenv("ARCQ_REPACKED_STREAM")) : 0;   // tuning / A-B only
+  if (a.M > 16) return gemm_repacked_mid(a, RW, RSF, stream);
   if (use_stream) return gemm_repacked_stream(a, RW, RSF, stream);
   const bool silu = a.epilogue == kEpiSiluMul;              // here: D stays gate|up, absmax_slots gets max |silu(g) * u| per row block
   if (silu && (!a.absmax_slots || (a.N % 4) || a.bias || a.residual || a.out_dtype != ARCQ_OUT_BF16))

@@ -180,7 +180,6 @@ template <int kSrc, int kOut, int kVariant>
 __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const a_img = smem;
-  float* const scratch = reinterpret_cast<float*>(smem);                            // kSrcRms: [M][512] partial sums, BEFORE the image exists
   float* const slots = reinterpret_cast<float*>(smem + p.slot_off);                 // partial tiles; slot_off == 0: aliases the image
   unsigned char* const xstage = smem + p.stage_off;                                 // [M (+1: norm weight)][xrow_bytes]
   float* const misc = reinterpret_cast<float*>(smem + p.misc_off);
@@ -205,9 +204,14 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
   ARCQ_STAMP(0);
   ARCQ_STAMP_RT(10);
 
-  // ---- every independent prologue load FIRST (a wave's loads return in order: issued behind the weights they would arrive
-  //      with them, at HBM instead of L2 latency)
-  const int G = p.KQ >> 4, Ptail = (p.KQ - p.KE) >> 4;
+  // ---- prologue loads.  kSrcPacked: the packed activations are requested first, the weights right behind them (inline-asm loads with
+  //      a hand-counted wait: hipcc would otherwise wait for the whole first task).  kSrcRms / kSrcDyn ("activations first"): X, the norm
+  //      weight, the reorder_index and the abs-max words are requested AND AWAITED before the first weight load is issued.  A CU's
+  //      vector memory pipeline serves its requests in order: behind the first task of 16 waves (192 KB per CU, 49 MB over the chip)
+  //      the 28 KB of activations came back after 2 400 (o_proj) ... 7 000 cycles (gate|up), and the quantiser prologue -- the
+  //      kernel's critical path on every decode shape -- could not start; alone they are back at L2 / Infinity-Cache latency, and the
+  //      weight stream loses those few hundred cycles at its start, once.
+  const int G = p.KQ >> 4, Ptail = (p.KQ - p.KE) >> 4, Rg = G - Ptail;   // groups per row; first group with a residual twin; their number
   constexpr int kPre = 2;
   uint4 pre_q[kPre];
   uint32_t pre_s[kPre];
@@ -215,6 +219,20 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
   uint32_t pre_slot[4] = {0, 0, 0, 0};
   const int upr = P * 8, real = p.K >> 5, atoms_k = p.K >> 6;       // kSrcPacked: image units (32 elements) per token row: padded / real
   const int chunks = p.KQ >> 3;                                     // kSrcRms / kSrcDyn: 16-byte chunks per row
+  // quantiser tasks of the fused sources: [0, M G) = (token, group) primaries, then [M G, M G + M Rg) = the residual twins of the last
+  // Rg groups of every token -- tasks of their own, so that no wave quantises three groups where the others quantise one (as lanes of
+  // the primary's wave they made that wave the workgroup's critical path: 2 500 cycles at the barrier behind the quantiser)
+  const int ntask_q = p.M * (G + Rg);
+  auto qtask = [&](int t, int& m, int& g) __attribute__((always_inline)) -> bool {
+    if (t < p.M * G) { m = t / G; g = t - m * G; return false; }
+    const int r = t - p.M * G;                               // only reached with Rg > 0
+    m = r / Rg; g = Ptail + (r - m * Rg);
+    return true;
+  };
+  // kSrcRms: wave w < M stages token w and forms its sum of squares in the reference's association order without leaving the wave:
+  // lane l plays the reference's threads l + 64 j (rmsnorm.cu:113-131: thread v adds the 16 squares of chunks v and KQ/16 + v)
+  // (64 registers of X per lane: consumed -- staged in LDS, squares summed -- BEFORE the weight ring claims its 54)
+  float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if constexpr (kSrc == kSrcPacked) {
     const int units = p.M * upr;
 #pragma unroll
@@ -225,29 +243,68 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
       pre_s[j] = asm_load_b32(p.SFA + sf_atom_offset(m, c >> 1, atoms_k));   // the atom's 4 bytes
     }
   } else {
-    // every asm load is UNCONDITIONAL (a conditionally defined register is merged with its default by a copy -- of a register
-    // whose load is still in flight): operands that are not needed are clamped to something valid and ignored later
-    {
-      // virtual thread t < M * KQ/16 owns chunks v and KQ/16 + v of row m = t / (KQ/16): the pair whose 16 squares the
-      // reference's RMSNorm adds sequentially (rmsnorm.cu:113-131), so the sum of squares is formed from these registers
-      const int bdx = chunks >> 1;
+    const int bdx = chunks >> 1;
+    if constexpr (kSrc == kSrcRms) {
+      pre_wn = *reinterpret_cast<const uint4*>(p.Wn + (size_t)min(tid, chunks - 1) * 8);
+    } else {
+      // kSrcDyn: thread t < M * KQ/16 owns chunks v and KQ/16 + v of row t / (KQ/16) (no order to keep: abs-max)
       const int vt = min(tid, p.M * bdx - 1), m = vt / bdx, v = vt - m * bdx;
-      pre_q[0] = asm_load_b128(p.X + ((size_t)m * chunks + v) * 8);
-      pre_q[1] = asm_load_b128(p.X + ((size_t)m * chunks + bdx + v) * 8);
-      pre_s[0] = pre_s[1] = 0;
-      if constexpr (kSrc == kSrcRms) pre_wn = asm_load_b128(p.Wn + (size_t)min(tid, chunks - 1) * 8);
-    }
-    {                                                        // reorder_index of this thread's first group
-      const int g = min(tid, p.M * G - 1) % G;
-      pre_i0 = asm_load_b128(p.idx + (size_t)g * 16);
-      pre_i1 = asm_load_b128(p.idx + (size_t)g * 16 + 8);
-    }
-    if constexpr (kSrc == kSrcDyn) {
+      pre_q[0] = *reinterpret_cast<const uint4*>(p.X + ((size_t)m * chunks + v) * 8);
+      pre_q[1] = *reinterpret_cast<const uint4*>(p.X + ((size_t)m * chunks + bdx + v) * 8);
       const uint32_t* sl = p.in_slots ? p.in_slots : reinterpret_cast<const uint32_t*>(p.X);
       const int ns = p.in_slots ? p.n_in_slots : 1;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) pre_slot[j] = asm_load_b32(sl + min(tid + j * kStThreads, ns - 1));
+      for (int j = 0; j < 4; ++j) pre_slot[j] = sl[min(tid + j * kStThreads, ns - 1)];
     }
+    {                                                        // reorder_index of this thread's first quantiser task
+      int m, g;
+      qtask(min(tid, ntask_q - 1), m, g);
+      pre_i0 = *reinterpret_cast<const uint4*>(p.idx + (size_t)g * 16);
+      pre_i1 = *reinterpret_cast<const uint4*>(p.idx + (size_t)g * 16 + 8);
+    }
+    if constexpr (kSrc == kSrcRms) {
+      // ---- (a) token `wave` (M <= 16 = waves): stage the row in LDS and add the squares, thread by thread of the reference
+      if (wave < p.M) {
+        const uint16_t* xrow = p.X + (size_t)wave * p.KQ;
+        uint16_t* row = reinterpret_cast<uint16_t*>(xstage + (size_t)wave * p.xrow_bytes);
+        uint4 xa[8], xb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (64 * j < bdx) {                                // wave-uniform
+            const int v = min(lane + 64 * j, bdx - 1);
+            xa[j] = *reinterpret_cast<const uint4*>(xrow + (size_t)v * 8);
+            xb[j] = *reinterpret_cast<const uint4*>(xrow + (size_t)(bdx + v) * 8);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int v = lane + 64 * j;
+          if (v < bdx) {                                     // (implies 64 j < bdx: xa[j] / xb[j] were loaded)
+            lds_store_chunk(row, v, xa[j]);
+            lds_store_chunk(row, bdx + v, xb[j]);
+            const uint32_t w8[8] = {xa[j].x, xa[j].y, xa[j].z, xa[j].w, xb[j].x, xb[j].y, xb[j].z, xb[j].w};
+            float acc = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float a = bf16_bits_to_f32(w8[e] & 0xffffu), b = bf16_bits_to_f32(w8[e] >> 16);
+              acc = acc + a * a;
+              acc = acc + b * b;
+            }
+            s8[j] = acc;                                     // absent partners of the tree stay 0.0f: x + 0.0f is x
+          }
+        }
+      }
+    }
+    // a use of every loaded register: hipcc waits for all of them HERE (nothing else is in flight), not behind the weights below
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (kSrc == kSrcRms) {
+      asm_tie(pre_wn);
+    } else {
+      asm_tie(pre_q[0]); asm_tie(pre_q[1]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm_tie(pre_slot[j]);
+    }
+    asm_tie(pre_i0); asm_tie(pre_i1);
   }
   __builtin_amdgcn_sched_barrier(0);
 
@@ -291,14 +348,13 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
   };
   load_task();
   __builtin_amdgcn_sched_barrier(0);
-  // the prologue's own loads are older than the c units just issued: retire exactly them
-  asm_wait_behind_units(c);
+  if constexpr (kSrc == kSrcPacked) {
+    // the prologue's own loads are older than the c units just issued: retire exactly them
+    asm_wait_behind_units(c);
 #pragma unroll
-  for (int j = 0; j < kPre; ++j) { asm_tie(pre_q[j]); asm_tie(pre_s[j]); }
-  asm_tie(pre_wn); asm_tie(pre_i0); asm_tie(pre_i1);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) asm_tie(pre_slot[j]);
-  __builtin_amdgcn_sched_barrier(0);
+    for (int j = 0; j < kPre; ++j) { asm_tie(pre_q[j]); asm_tie(pre_s[j]); }
+    __builtin_amdgcn_sched_barrier(0);
+  }
   ARCQ_STAMP(1);
   if (ntasks <= 1) prefetch_epilogue();                       // (after the counted wait above: it assumes 3 loads per unit behind it)
 
@@ -316,13 +372,42 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
                      *reinterpret_cast<const uint32_t*>(p.SFA + sf_atom_offset(m, cc >> 1, atoms_k)));
     }
   } else {
-    // ---- (a) stage X (and the norm weight) in LDS; on the way: abs-max of X (kSrcDyn without abs-max words) or the per-thread
-    //      sums of squares in the reference's association order (kSrcRms: virtual thread v adds the 16 squares of chunks v and
-    //      bdx + v sequentially, rmsnorm.cu:113-131; oracle rms_sumsq)
+    // ---- (a) stage X (and the norm weight) in LDS; on the way: abs-max of X (kSrcDyn without abs-max words) or, kSrcRms, the sums
+    //      of squares in the reference's association order (thread v adds the 16 squares of chunks v and bdx + v sequentially,
+    //      rmsnorm.cu:113-131; oracle rms_sumsq), formed from the very registers that loaded X
     uint32_t amax = 0;
-    {
-      const int bdx = chunks >> 1, vthreads = p.M * bdx;
-      const bool need = p.stage || kSrc == kSrcRms || (kSrc == kSrcDyn && !p.in_slots);
+    const int bdx = chunks >> 1;                             // = G: the reference's block size
+    if constexpr (kSrc == kSrcRms) {
+      if (wave < p.M) {
+        // ---- (b) the reference's fixed tree s[v] += s[v + stride], stride = 256 ... 1 (rmsnorm.cu:133-154), inside the wave: lane l
+        //      holds s[l + 64 j]; strides 256 / 128 / 64 combine its own registers, 32 and 16 are shuffles, 8 .. 1 DPP row shifts
+        //      (the same scheme as quantize.hip's rms_sumsq_tree, byte-checked against the oracle)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s8[j] = s8[j] + s8[j + 4];                          // stride 256
+        s8[0] = s8[0] + s8[2];                                                          // stride 128
+        s8[1] = s8[1] + s8[3];
+        float z = s8[0] + s8[1];                                                        // stride 64
+        const float up = __shfl_down(z, 32, 64);
+        if (lane < 32) z = z + up;                                                      // stride 32
+        float val = lane < 32 ? z : 0.0f;
+        val += __shfl_down(val, 16, 64);                                                // lane 0's cone = the reference's
+        val += dpp_row_shl<8>(val);                                                     // strides 8 .. 1 stay inside lane 0's row of 16:
+        val += dpp_row_shl<4>(val);                                                     // DPP (lane i <- lane i + n, 0 beyond the row)
+        val += dpp_row_shl<2>(val);
+        val += dpp_row_shl<1>(val);
+        if (lane == 0) {
+          const float var = val / (float)p.KQ + p.eps;                                  // rmsnorm.cu:157
+          misc[32 + wave] = (float)(1.0 / sqrt((double)var));                           // oracle assumption A4
+        }
+      }
+      if (tid < chunks) lds_store_chunk(reinterpret_cast<uint16_t*>(xstage + (size_t)p.M * p.xrow_bytes), tid, pre_wn);
+      for (int cidx = tid + kStThreads; cidx < chunks; cidx += kStThreads)              // KQ > 8192 never reaches the RMSNorm path
+        lds_store_chunk(reinterpret_cast<uint16_t*>(xstage + (size_t)p.M * p.xrow_bytes), cidx, *reinterpret_cast<const uint4*>(p.Wn + (size_t)cidx * 8));
+      ARCQ_STAMP(8);
+      __syncthreads();                                       // staged rows, norm weight and rstd visible
+    } else {
+      const int vthreads = p.M * bdx;
+      const bool need = p.stage || !p.in_slots;
       if (need) {
         for (int t = tid; t < vthreads; t += kStThreads) {
           const int m = t / bdx, v = t - m * bdx;
@@ -336,21 +421,9 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
             lds_store_chunk(row, v, d0);
             lds_store_chunk(row, bdx + v, d1);
           }
-          if (kSrc == kSrcDyn) amax = absmax_bits_chunk(d1, absmax_bits_chunk(d0, amax));
-          if (kSrc == kSrcRms) {
-            const uint32_t w8[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-            float acc = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const float a = bf16_bits_to_f32(w8[j] & 0xffffu), b = bf16_bits_to_f32(w8[j] >> 16);
-              acc = acc + a * a;
-              acc = acc + b * b;
-            }
-            scratch[m * 512 + v] = acc;
-          }
+          amax = absmax_bits_chunk(d1, absmax_bits_chunk(d0, amax));
         }
       }
-      if (kSrc == kSrcRms && tid < chunks) lds_store_chunk(reinterpret_cast<uint16_t*>(xstage + (size_t)p.M * p.xrow_bytes), tid, pre_wn);
     }
     float dyn_scale = 1.0f;
     if constexpr (kSrc == kSrcDyn) {
@@ -361,6 +434,7 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
       }
       amax = wave_max_u32(amax);
       if (lane == 0) misc_u[wave] = amax;
+      ARCQ_STAMP(8);
       __syncthreads();                                       // (also publishes the staged rows)
       uint32_t mbits = 0;
 #pragma unroll
@@ -371,52 +445,20 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
       dyn_scale = round_to_bf16(dyn_scale);                  // torch divides a bf16 tensor by the scale rounded to bf16
     }
     const DynDiv dyn_div(dyn_scale, kSrc == kSrcDyn);
-    ARCQ_STAMP(8);
-    if constexpr (kSrc == kSrcRms) {
-      // ---- (b) sum of squares per token in the reference's association order (rmsnorm.cu:113-154; oracle rms_sumsq):
-      //      virtual thread v < bdx = KQ/16 adds the 16 squares of chunks v and bdx + v sequentially; then the fixed tree
-      //      s[v] += s[v + stride], stride = 256 ... 1, evaluated by ONE wave per token without a barrier: lane l holds
-      //      s[l + 64 j], j < 8 (absent partners are 0.0f: x + 0.0f is x), strides 256 / 128 / 64 combine its own registers,
-      //      32 and below are shuffles (the same scheme as quantize.hip's rms_sumsq_tree, byte-checked against the oracle)
-      const int bdx = G;
-      __syncthreads();                                       // staged rows and the per-thread sums visible
-      if (wave < p.M) {                                      // M <= 16 = waves: token `wave`
-        float s8[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s8[j] = lane + 64 * j < bdx ? scratch[wave * 512 + lane + 64 * j] : 0.0f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s8[j] = s8[j] + s8[j + 4];                        // stride 256
-        s8[0] = s8[0] + s8[2];                                                        // stride 128
-        s8[1] = s8[1] + s8[3];
-        float z = s8[0] + s8[1];                                                      // stride 64
-        const float up = __shfl_down(z, 32, 64);
-        if (lane < 32) z = z + up;                                                    // stride 32
-        float val = lane < 32 ? z : 0.0f;
-        val += __shfl_down(val, 16, 64);                                              // lane 0's cone = the reference's
-        val += dpp_row_shl<8>(val);                                                   // strides 8 .. 1 stay inside lane 0's row of 16:
-        val += dpp_row_shl<4>(val);                                                   // DPP (lane i <- lane i + n, 0 beyond the row)
-        val += dpp_row_shl<2>(val);                                                   // instead of four LDS-crossbar permutes
-        val += dpp_row_shl<1>(val);
-        if (lane == 0) {
-          const float var = val / (float)p.KQ + p.eps;                                // rmsnorm.cu:157
-          misc[32 + wave] = (float)(1.0 / sqrt((double)var));                         // oracle assumption A4
-        }
-      }
-      __syncthreads();                                       // rstd visible; `scratch` may now be overwritten by the image
-    }
     ARCQ_STAMP(9);
-    // ---- (c) quantise group by group straight into the image; the K padding is zero
+    // ---- (c) quantise task by task straight into the image; the K padding is zero
     const uint16_t* wn_lds = reinterpret_cast<const uint16_t*>(xstage + (size_t)p.M * p.xrow_bytes);
-    // `p.stage` and the divider's fast path are uniform over the launch: the group loop is instantiated per combination (as
+    // `p.stage` and the divider's fast path are uniform over the launch: the task loop is instantiated per combination (as
     // branches inside the 16-element gather they cost a scalar branch and a FULL wait per element -- sixteen serialised LDS
     // round trips per group)
     const st_u32x4 pi0 = {pre_i0.x, pre_i0.y, pre_i0.z, pre_i0.w}, pi1 = {pre_i1.x, pre_i1.y, pre_i1.z, pre_i1.w};
     auto run_groups = [&](auto stage_tag, auto fast_tag) __attribute__((always_inline)) {
     constexpr bool kStage = decltype(stage_tag)::value, kFast = decltype(fast_tag)::value;
-    for (int t = tid; t < p.M * G; t += kStThreads) {
-      const int m = t / G, g = t - m * G;
+    for (int t = tid; t < ntask_q; t += kStThreads) {
+      int m, g;
+      const bool twin = qtask(t, m, g);                      // the residual twin of (m, g): uniform over a wave except at one boundary
       st_u32x4 i0 = pi0, i1 = pi1;                           // (native vectors: a HIP uint4 captured by the lambda lands in scratch)
-      if (t != tid) {                                        // later groups of this thread (M * KQ > 16 K elements)
+      if (t != tid) {                                        // later tasks of this thread (M * KQ > 16 K elements)
         i0 = *reinterpret_cast<const st_u32x4*>(p.idx + (size_t)g * 16);
         i1 = *reinterpret_cast<const st_u32x4*>(p.idx + (size_t)g * 16 + 8);
       }
@@ -456,10 +498,10 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
         const int g1 = g & ~1;
         pos = g1 + (g1 > Ptail ? g1 - Ptail : 0) + (g & 1);
       }
-      if (g < Ptail) {
+      if (!twin) {                                             // the primary's codes do not depend on kResid (quantize_group)
         image_put_group(a_img, p, m, pos, quantize_group<false, kVariant>(v));
       } else {                                                 // residual channels: reorder.cu:166-198, 499-550
-        image_put_group(a_img, p, m, pos, quantize_group<true, kVariant>(v));
+        quantize_group<true, kVariant>(v);                     // v <- bf16(v - q * S)
         image_put_group(a_img, p, m, pos + (kVariant == ARCQ_VARIANT_G16 ? 1 : 2), quantize_group<false, kVariant>(v));
       }
     }
@@ -628,7 +670,6 @@ static int stream_geometry(int src, int64_t M, int64_t N, int64_t K, int64_t KQ,
   g->grid = stream_grid(g->row_blocks);
   g->a_stride = g->pairs * 512 + 16;                        // + 16: token rows start in different banks
   int64_t img = M * (int64_t)g->a_stride;
-  if (src == kSrcRms && img < M * 2048) img = M * 2048;     // reduction scratch [M][512] floats lives here before the image
   img = (img + 15) & ~(int64_t)15;
   g->xrow_bytes = src == kSrcPacked ? 0 : (int)((lds_row_bytes((size_t)KQ) + 15) & ~(size_t)15);
   const int64_t rows = src == kSrcPacked ? 0 : M + (src == kSrcRms ? 1 : 0);

@@ -29,8 +29,8 @@ def _gpu_count():
 # Tests that must START PROGRAMS on the GPU box (tests/test_bench_launch_gpu.py: `python bench.py --gpus 2`) do it through a fork
 # server that is started here, while this process is still GPU-free: its children never inherit a GPU-initialised state.
 FORKSERVER = None
-if _gpu_count() > 0:
-    import multiprocessing as _mp
+import multiprocessing as _mp                              # noqa: E402
+if _mp.parent_process() is None and _gpu_count() > 0:      # the pytest process itself, never a child that imports this module
     from multiprocessing import forkserver as _fs
     FORKSERVER = _mp.get_context("forkserver")
     _fs.ensure_running()

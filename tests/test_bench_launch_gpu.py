@@ -7,21 +7,15 @@ The programs are started through the fork server of tests/conftest.py (this pyte
 exec)."""
 import json
 import os
-import subprocess
 import sys
 
 import pytest
 
 from tests import conftest
+from tests.util import run_program
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def _run(cmd, env, out_path):
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT, timeout=900)
-    with open(out_path, "w") as f:
-        json.dump({"rc": r.returncode, "stdout": r.stdout, "stderr": r.stderr[-4000:]}, f)
 
 
 def _start(cmd, tmp_path):
@@ -29,7 +23,7 @@ def _start(cmd, tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(ARCQ_BENCH_ONE_DEVICE="1", ARCQ_BENCH_BACKEND="gloo")
     out = str(tmp_path / "result.json")
-    p = conftest.FORKSERVER.Process(target=_run, args=(cmd, env, out))
+    p = conftest.FORKSERVER.Process(target=run_program, args=(cmd, env, ROOT, out))
     p.start()
     p.join(1000)
     assert p.exitcode == 0, f"runner exit code {p.exitcode}"

@@ -490,7 +490,10 @@ def test_repacked_weight_gemm_equals_the_reference_layout_gemm():
     ag = _agemm()
     cases = [(1, 512, 256, 64, O.G16), (4, 100, 256, 64, O.G16), (3, 1000, 64, 0, O.G16), (16, 272, 1024, 64, O.G16),
              (8, 777, 512, 64, O.G16), (4, 3584, 3584, 64, O.G32), (2, 52000, 256, 64, O.G16), (5, 5120, 384, 0, O.G16),
-             (4, 256, 18944, 64, O.G32)]        # the last: a 153.7 KB activation image (Qwen2.5-7B down-projection at bs=4)
+             (4, 256, 18944, 64, O.G32),        # a 153.7 KB activation image (Qwen2.5-7B down-projection at bs=4)
+             # decode batches, 16 < M <= 64: the weight is still read once, activations stay packed in LDS (gemm_rowmid.hip)
+             (17, 128, 256, 64, O.G16), (32, 1000, 2048, 64, O.G16), (33, 516, 2048, 0, O.G16), (48, 777, 512, 64, O.G16),
+             (64, 272, 1024, 64, O.G16), (40, 3584, 3584, 64, O.G32), (64, 4096, 4096, 64, O.G16), (32, 4096, 4096, 0, O.G16)]
     for (M, N, KQ, KE, variant) in cases:
         K = KQ + KE
         assert ag.repacked_supported(M, N, K)
@@ -512,7 +515,7 @@ def test_repacked_weight_gemm_equals_the_reference_layout_gemm():
         want16 = res + (got32.to(torch.bfloat16) + bias)          # the reference's op order: matmul -> + bias -> x + y, each in bf16
         got16 = ag.matmul_repacked(A, RW, SFA, RSF, dev_scale, N, scale_host=0.5, bias=bias, residual=res)
         assert torch.equal(got16, want16), (M, N, K)
-    assert not ag.repacked_supported(17, 256, 256) and not ag.repacked_supported(5, 256, 19008)
+    assert not ag.repacked_supported(65, 256, 256) and not ag.repacked_supported(5, 256, 19008) and not ag.repacked_supported(32, 256, 14400)
     with pytest.raises(RuntimeError):
         ag.matmul_repacked(A, RW[:-1], SFA, RSF, alpha, N)
 
@@ -653,6 +656,11 @@ def test_gemm_fuzz_random_shapes_against_fp64_matmul():
         assert bool((err <= 2e-6 * wabs + 1e-30).all()), (case, M, N, K, float((err / (wabs + 1e-30)).max()))
         got16 = ag.matmul(A, B, SFA, SFB, alpha).double()
         assert bool(((got16 - want).abs() <= want.abs() * 2.0 ** -8 + 2e-6 * wabs + 1e-30).all()), (case, M, N, K)
+        if ag.repacked_supported(M, N, K):                 # M <= 16: fp16 image; 16 < M <= 64: packed activations in LDS
+            RW, RSF = ag.repack_w(B, SFB)
+            gotr = ag.matmul_repacked(A, RW, SFA, RSF, alpha, N, out_dtype=torch.float32).double()
+            errr = (gotr - want).abs()
+            assert bool((errr <= 2e-6 * wabs + 1e-30).all()), ("repacked", case, M, N, K, float((errr / (wabs + 1e-30)).max()))
 
 
 # ------------------------------------------------------------------------------------------------ fused decode linears

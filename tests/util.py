@@ -33,3 +33,13 @@ def prescale(x: torch.Tensor):
 def random_perm(K, seed):
     g = torch.Generator().manual_seed(seed)
     return torch.randperm(K, generator=g).to(torch.int16)
+
+
+def run_program(cmd, env, cwd, out_path, timeout=900):
+    """Target of a fork-server process (tests/conftest.py FORKSERVER): run a program from a process that never touched the GPU and
+    leave its exit code and output in a JSON file.  Lives here so that the child imports nothing but this module."""
+    import json
+    import subprocess
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=cwd, timeout=timeout)
+    with open(out_path, "w") as f:
+        json.dump({"rc": r.returncode, "stdout": r.stdout, "stderr": r.stderr[-4000:]}, f)
