@@ -220,6 +220,148 @@ __global__ __launch_bounds__(kRbThreads, 4) void gemm_rowblock_kernel(RowblockPa
   }
 }
 
+// ---- the same contraction WITHOUT the LDS image (kernel "direct") ------------------------------------------------------------------
+// For small M the image is a detour on the critical path of a latency-bound kernel: activations -> dequantise -> LDS -> barrier ->
+// first MFMA (config[1]: ~2 000 of 9 500 cycles, and every wave waits for the slowest one's activation loads), and for large K it
+// costs the kernel its occupancy (Qwen2.5-7B down projection at bs = 4: a 154 KB image = ONE 8-wave workgroup per CU).  Here every
+// lane fetches its MFMA B operand itself: lane (token rl, quarter q) of a wave loads the 16 packed bytes [16 q, 16 q + 16) of token
+// min(rl, M - 1)'s row for each 128-element tile of its K slice, and the two scale bytes of its groups, next to the weight tile
+// (requested BEFORE it: a wave's loads return in order), and dequantises them in registers exactly as the weights.  No LDS, no
+// barrier before the K loop; the packed activations are a few KB per token and L2-resident (every workgroup reads the same bytes).
+// Costs per tile pair: 4 more loads per lane (7 instead of 3) and 80 more conversion instructions -- which a latency-bound kernel has.
+struct RowblockActRegs {  // activations of one tile pair for this lane: 2 x 16 bytes of codes, 2 x 2 scale bytes
+  rb_u32x4 a0, a1;
+  uint32_t s0, s1;
+};
+
+template <bool kSiluAbsmax>
+__global__ __launch_bounds__(kRbThreads, 2) void gemm_rowblock_direct_kernel(RowblockParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* const red = reinterpret_cast<float*>(smem);    // [8 waves][64][4] when slices > 1
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, rl = lane & 15;
+  const int bpw = kRbWaves / p.slices;                    // row blocks per workgroup
+  const int rb = blockIdx.x * bpw + wave / p.slices;
+  const int slice = wave % p.slices;
+  const bool active = rb < p.row_blocks;
+  int pr_begin, pr_count;
+  rowblock_slice_range(p.pairs, p.slices, slice, &pr_begin, &pr_count);
+  const int npairs = active ? pr_count : 0;
+  const float alpha = p.alpha_host * (p.alpha_dev ? *p.alpha_dev : 1.0f);
+
+  const int rbc = active ? rb : 0;
+  const int pr_load = rowblock_load_base(pr_begin, npairs);   // never past the row block's own pairs
+  const uint8_t* wp = p.RW + ((size_t)rbc * p.pairs + pr_load) * 2048 + lane * 16;
+  const uint8_t* sp = p.RSF + ((size_t)rbc * p.pairs + pr_load) * 256 + lane * 4;
+  // activations of this lane: token min(rl, M - 1) (tokens >= M: any row, never stored); K padded to 256 in the weight only, so
+  // tiles and atoms beyond K are clamped to the last real one and meet zero weight scales
+  const int tok = min(rl, p.M - 1);
+  const int atoms_k = p.K >> 6, tiles_k = p.K >> 7;          // K % 64 == 0: the last tile may be half (one atom)
+  const uint8_t* arow = p.A + (size_t)tok * (p.K >> 1) + q * 16;
+  const uint8_t* srow = p.SFA + sf_atom_offset(tok, 0, atoms_k) + (q & 1) * 2;
+  const int last = npairs > 0 ? npairs - 1 : 0;
+  int issued = 0;
+  auto issue = [&](RowblockRegs& r, RowblockActRegs& x) __attribute__((always_inline)) {   // unpredicated; the cursor stops at the last pair
+    const int i = min(issued, last);
+    const int t0 = 2 * (pr_load + i), t1 = t0 + 1;                      // the pair's two 128-element tiles
+    // a tile past K (padding): bytes of the last real tile (any finite codes), its weight scales are zero.  The second half of a
+    // trailing half tile (K % 128 == 64) lies past the row as well: quarters q >= 2 re-read quarters q - 2.
+    const int halfk = (p.K & 64) ? 1 : 0;
+    auto a_off = [&](int t) __attribute__((always_inline)) -> size_t {
+      const int tc = min(t, tiles_k - 1 + halfk);
+      size_t off = (size_t)tc * 64;
+      if (halfk && tc == tiles_k && q >= 2) off -= 32;                  // (only the half tile; its groups 4 .. 7 have zero weight scales)
+      return off;
+    };
+    auto s_off = [&](int t) __attribute__((always_inline)) -> size_t {
+      const int atom = min(2 * t + (q >> 1), atoms_k - 1);
+      return (size_t)atom * 512;
+    };
+    x.a0 = *reinterpret_cast<const rb_u32x4*>(arow + a_off(t0));
+    x.a1 = *reinterpret_cast<const rb_u32x4*>(arow + a_off(t1));
+    x.s0 = *reinterpret_cast<const uint16_t*>(srow + s_off(t0));
+    x.s1 = *reinterpret_cast<const uint16_t*>(srow + s_off(t1));
+    // a weight byte is read once per launch by one CU: non-temporal loads (gemm_common.hpp)
+    r.b0 = ARCQ_WLOAD(reinterpret_cast<const rb_u32x4*>(wp + (size_t)i * 2048));
+    r.b1 = ARCQ_WLOAD(reinterpret_cast<const rb_u32x4*>(wp + (size_t)i * 2048 + 1024));
+    r.s = ARCQ_WLOAD(reinterpret_cast<const uint32_t*>(sp + (size_t)i * 256));
+    ++issued;
+  };
+  RowblockRegs r0, r1, r2;
+  RowblockActRegs x0, x1, x2;
+  issue(r0, x0);
+  issue(r1, x1);
+  issue(r2, x2);
+
+  // bias / residual of this wave's output tile (the slice-0 wave finishes the row block), behind the ring's first loads
+  typedef uint32_t rb_u32x2 __attribute__((ext_vector_type(2)));
+  rb_u32x2 ep_bias = {0, 0}, ep_res = {0, 0};
+  const bool ep_pre = !kSiluAbsmax && (p.N & 3) == 0 && (p.bias || p.residual);
+  if (ep_pre && slice == 0 && active && rl < p.M && rb * 16 + 4 * q < p.N) {
+    const int n0p = rb * 16 + 4 * q;
+    if (p.bias) ep_bias = *reinterpret_cast<const rb_u32x2*>(p.bias + n0p);
+    if (p.residual) ep_res = *reinterpret_cast<const rb_u32x2*>(p.residual + (size_t)rl * p.N + n0p);
+  }
+
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int done = 0;
+  auto tile = [&](rb_u32x4 b, uint32_t s16, rb_u32x4 a, uint32_t as16) __attribute__((always_inline)) {
+    const f16x2 t0 = sf_pair_at(as16, 0), t1 = sf_pair_at(as16, 8);
+    const Frag8 a0 = dequant8(a.x, t0), a1 = dequant8(a.y, t0), a2 = dequant8(a.z, t1), a3 = dequant8(a.w, t1);
+    const f16x2 s0 = sf_pair_at(s16, 0), s1 = sf_pair_at(s16, 8);
+    const Frag8 b0 = dequant8(b.x, s0), b1 = dequant8(b.y, s0), b2 = dequant8(b.z, s1), b3 = dequant8(b.w, s1);
+    // weights are the MFMA A operand (rows = weight rows), activations the B operand (columns = tokens)
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0.v, a0.v, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1.v, a1.v, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b2.v, a2.v, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b3.v, a3.v, acc, 0, 0, 0);
+  };
+  auto step = [&](RowblockRegs& r, RowblockActRegs& x) __attribute__((always_inline)) {
+    tile(r.b0, r.s, x.a0, x.s0);
+    tile(r.b1, r.s >> 16, x.a1, x.s1);
+    issue(r, x);                                            // refill: three pairs ahead
+    __builtin_amdgcn_sched_barrier(0);
+    ++done;
+  };
+#pragma unroll 1
+  while (done + 3 <= npairs) {
+    step(r0, x0);
+    step(r1, x1);
+    step(r2, x2);
+  }
+  if (done < npairs) step(r0, x0);
+  if (done < npairs) step(r1, x1);
+
+  // ---- lane holds C[token = rl][row = 16 rb + 4q + e]; add the K slices of a row block through LDS
+  float sum[4] = {acc[0], acc[1], acc[2], acc[3]};
+  if (p.slices > 1) {
+    *reinterpret_cast<float4*>(red + (wave * 64 + lane) * 4) = make_float4(sum[0], sum[1], sum[2], sum[3]);
+    __syncthreads();
+    if (slice != 0) return;
+    for (int s2 = 1; s2 < p.slices; ++s2) {
+      const float4 v = *reinterpret_cast<const float4*>(red + ((wave + s2) * 64 + lane) * 4);
+      sum[0] += v.x; sum[1] += v.y; sum[2] += v.z; sum[3] += v.w;
+    }
+  }
+  const int n0 = rb * 16 + 4 * q;
+  if (active && rl < p.M && n0 < p.N) {
+    if (ep_pre) finish4_pre<uint32_t>(p, alpha, rl, n0, sum, make_uint2(ep_bias.x, ep_bias.y), make_uint2(ep_res.x, ep_res.y));
+    else finish4<uint32_t>(p, alpha, rl, n0, sum);
+  }
+  if constexpr (kSiluAbsmax) {                              // N % 4 == 0, bf16 out, no bias / residual (checked by the launcher)
+    uint32_t m = 0;
+    if (active && rl < p.M && n0 < p.N) {
+      const uint32_t b0 = f32_to_bf16_bits(alpha * sum[0]), b1 = f32_to_bf16_bits(alpha * sum[1]);
+      const uint32_t b2 = f32_to_bf16_bits(alpha * sum[2]), b3 = f32_to_bf16_bits(alpha * sum[3]);
+      m = max(silu_mul_bf16(b0, b1) & 0x7fffu, silu_mul_bf16(b2, b3) & 0x7fffu);
+    }
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, sh, 64));
+    if (lane == 0 && active) p.silu_slots[rb] = m;
+  }
+}
+
 // Repacked sizes: rows padded to 16, K to 256.
 static int64_t rowblock_pairs(int64_t K) { return (K + 255) / 256; }
 int64_t gemm_repacked_w_bytes(int64_t N, int64_t K) { return ((N + 15) / 16) * rowblock_pairs(K) * 2048; }
@@ -240,6 +382,9 @@ int gemm_repacked_supported(int64_t M, int64_t N, int64_t K) {
   int stride;
   return rowblock_lds_bytes((int)M, K, 8, &stride) <= 160 * 1024 ? 1 : 0;
 }
+
+// which plain repacked shapes take the no-image kernel (measured on MI355X, tools/decode_stream_bench.py / midm_bench.py)
+static bool rowblock_use_direct(int M, int N, int64_t K) { return false; }
 
 int gemm_repacked(const GemmArgs& a, const uint8_t* RW, const uint8_t* RSF, hipStream_t stream) {
   static const int use_stream = getenv("ARCQ_REPACKED_STREAM") ? atoi(getenv("ARCQ_REPACKED_STREAM")) : 0;   // tuning / A-B only
@@ -272,6 +417,17 @@ int gemm_repacked(const GemmArgs& a, const uint8_t* RW, const uint8_t* RSF, hipS
     return ARCQ_OK;
   };
   static LdsOptIn lds_set[8];           // one per kernel instantiation, each per device
+  // the no-image kernel: ARCQ_ROWBLOCK_DIRECT=0/1 forces (A-B), default by shape (rowblock_use_direct)
+  static const int direct_env = getenv("ARCQ_ROWBLOCK_DIRECT") ? atoi(getenv("ARCQ_ROWBLOCK_DIRECT")) : -1;
+  const bool direct = direct_env >= 0 ? direct_env != 0 : rowblock_use_direct(a.M, a.N, a.K);
+  if (direct) {
+    const int dlds = s > 1 ? kRbWaves * 64 * 4 * (int)sizeof(float) : 0;
+    if (silu) hipLaunchKernelGGL(gemm_rowblock_direct_kernel<true>, dim3((unsigned)grid), dim3(kRbThreads), dlds, stream, p);
+    else hipLaunchKernelGGL(gemm_rowblock_direct_kernel<false>, dim3((unsigned)grid), dim3(kRbThreads), dlds, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_gemm_nvfp4_repacked: launch failed: %s", hipGetErrorString(e));
+    return ARCQ_OK;
+  }
   int rc;
   if (silu) {
     if (per_thread <= 1) rc = launch(gemm_rowblock_kernel<1, true>, &lds_set[4]);

@@ -201,6 +201,10 @@ static int rowmid_lds_bytes(int M, int64_t K, int slices, int tok, RowmidParams*
 // is NOT required -- one workgroup per CU is enough to stream (the launcher asks for what fits)
 int gemm_repacked_mid_supported(int64_t M, int64_t N, int64_t K) {
   if (M <= 16 || M > 64 || N < 1 || K < 64 || (K % 64)) return 0;
+  // three and four token tiles per weight unit are compute-bound (activation conversions + MFMA per unit); on large weights the
+  // LDS-tiled GEMM with its 64 x 256 tiles catches up: N = 37888, K = 3648: M = 48 53.7 vs 53.7 us, M = 64 67.0 vs 58.1 us
+  // (tools/midm_bench.py), while N = 10752 still gains at M = 64 (23.9 vs 26.6 us)
+  if (M > 32 && N * K > (int64_t)64 << 20) return 0;
   return rowmid_lds_bytes((int)M, K, 8, (int)((M + 15) / 16), nullptr) <= 160 * 1024 ? 1 : 0;
 }
 

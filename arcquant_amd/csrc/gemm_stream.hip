@@ -233,6 +233,8 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
   // lane l plays the reference's threads l + 64 j (rmsnorm.cu:113-131: thread v adds the 16 squares of chunks v and KQ/16 + v)
   // (64 registers of X per lane: consumed -- staged in LDS, squares summed -- BEFORE the weight ring claims its 54)
   float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int first_m = 0, first_g = 0;                             // this thread's first quantiser task (its reorder_index is prefetched)
+  bool first_twin = false;
   if constexpr (kSrc == kSrcPacked) {
     const int units = p.M * upr;
 #pragma unroll
@@ -257,10 +259,9 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
       for (int j = 0; j < 4; ++j) pre_slot[j] = sl[min(tid + j * kStThreads, ns - 1)];
     }
     {                                                        // reorder_index of this thread's first quantiser task
-      int m, g;
-      qtask(min(tid, ntask_q - 1), m, g);
-      pre_i0 = *reinterpret_cast<const uint4*>(p.idx + (size_t)g * 16);
-      pre_i1 = *reinterpret_cast<const uint4*>(p.idx + (size_t)g * 16 + 8);
+      first_twin = qtask(min(tid, ntask_q - 1), first_m, first_g);
+      pre_i0 = *reinterpret_cast<const uint4*>(p.idx + (size_t)first_g * 16);
+      pre_i1 = *reinterpret_cast<const uint4*>(p.idx + (size_t)first_g * 16 + 8);
     }
     if constexpr (kSrc == kSrcRms) {
       // ---- (a) token `wave` (M <= 16 = waves): stage the row in LDS and add the squares, thread by thread of the reference
@@ -338,15 +339,23 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
   int task_left = ntasks, done = 0;
   int c = ntasks > 0 ? (n + ntasks - 1) / ntasks : 0;       // units of the current task (wave-uniform)
   StreamRegs r0 = {}, r1 = {}, r2 = {}, r3 = {}, r4 = {}, r5 = {};
-  auto load_task = [&]() __attribute__((always_inline)) {
-    if (c > 0) load_unit(r0, done);
-    if (c > 1) load_unit(r1, done + 1);
-    if (c > 2) load_unit(r2, done + 2);
-    if (c > 3) load_unit(r3, done + 3);
-    if (c > 4) load_unit(r4, done + 4);
-    if (c > 5) load_unit(r5, done + 5);
+  auto load_task_part = [&](int lo, int hi) __attribute__((always_inline)) {      // units [lo, hi) of the current task
+    if (c > 0 && lo <= 0 && 0 < hi) load_unit(r0, done);
+    if (c > 1 && lo <= 1 && 1 < hi) load_unit(r1, done + 1);
+    if (c > 2 && lo <= 2 && 2 < hi) load_unit(r2, done + 2);
+    if (c > 3 && lo <= 3 && 3 < hi) load_unit(r3, done + 3);
+    if (c > 4 && lo <= 4 && 4 < hi) load_unit(r4, done + 4);
+    if (c > 5 && lo <= 5 && 5 < hi) load_unit(r5, done + 5);
   };
-  load_task();
+  auto load_task = [&]() __attribute__((always_inline)) { load_task_part(0, kTask); };
+  // The fused sources issue their first task in three parts, between the phases of the prologue: a 16-byte wave load occupies the
+  // CU's address pipeline for ~16 cycles, so 16 waves x 6 units x 3 loads held every wave in its issue sequence for 3 800 cycles
+  // (gate|up) before the quantiser could start.  Two units per wave keep HBM busy through a phase (64 KB per CU ~ 6 400 cycles).
+  constexpr int kPart = kSrc == kSrcPacked ? kTask : 2;
+  // kSrcRms: the waves that hold a token (wave < M) are the ones the workgroup's first barrier waits for (reduction tree, rstd): they
+  // issue NOTHING before it -- behind the other waves' loads their own issue sequence delayed the barrier by 2 000 - 4 000 cycles
+  const bool token_wave = kSrc == kSrcRms && wave < p.M;
+  if (!token_wave) load_task_part(0, kPart);
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (kSrc == kSrcPacked) {
     // the prologue's own loads are older than the c units just issued: retire exactly them
@@ -445,6 +454,8 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
       dyn_scale = round_to_bf16(dyn_scale);                  // torch divides a bf16 tensor by the scale rounded to bf16
     }
     const DynDiv dyn_div(dyn_scale, kSrc == kSrcDyn);
+    load_task_part(token_wave ? 0 : kPart, 2 * kPart);
+    __builtin_amdgcn_sched_barrier(0);
     ARCQ_STAMP(9);
     // ---- (c) quantise task by task straight into the image; the K padding is zero
     const uint16_t* wn_lds = reinterpret_cast<const uint16_t*>(xstage + (size_t)p.M * p.xrow_bytes);
@@ -455,10 +466,11 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
     auto run_groups = [&](auto stage_tag, auto fast_tag) __attribute__((always_inline)) {
     constexpr bool kStage = decltype(stage_tag)::value, kFast = decltype(fast_tag)::value;
     for (int t = tid; t < ntask_q; t += kStThreads) {
-      int m, g;
-      const bool twin = qtask(t, m, g);                      // the residual twin of (m, g): uniform over a wave except at one boundary
+      int m = first_m, g = first_g;
+      bool twin = first_twin;                                // the residual twin of (m, g): uniform over a wave except at one boundary
       st_u32x4 i0 = pi0, i1 = pi1;                           // (native vectors: a HIP uint4 captured by the lambda lands in scratch)
       if (t != tid) {                                        // later tasks of this thread (M * KQ > 16 K elements)
+        twin = qtask(t, m, g);
         i0 = *reinterpret_cast<const st_u32x4*>(p.idx + (size_t)g * 16);
         i1 = *reinterpret_cast<const st_u32x4*>(p.idx + (size_t)g * 16 + 8);
       }
@@ -469,7 +481,6 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
       float v[16];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        if (j == 4) __builtin_amdgcn_sched_barrier(0);         // two batches of LDS reads: 8 address + 8 value registers less
         const uint32_t ia = iw[j] & 0xffffu, ib = iw[j] >> 16;
         const uint32_t pw = lds_pad_pair(iw[j]), pa = pw & 0xffffu, pb = pw >> 16;
         float a, b;
@@ -515,6 +526,8 @@ __global__ __launch_bounds__(kStThreads) void gemm_stream_kernel(StreamParams p)
       if (dyn_div.fast) run_groups(std::false_type{}, std::true_type{});
       else run_groups(std::false_type{}, std::false_type{});
     }
+    load_task_part(2 * kPart, kTask);
+    __builtin_amdgcn_sched_barrier(0);
     const int pad_groups = P * 16 - (p.K >> 4);               // zero scale bytes of the repacked weight meet zeros here
     for (int t = tid; t < p.M * pad_groups; t += kStThreads) {
       const int m = t / pad_groups, g = (p.K >> 4) + (t - m * pad_groups);
