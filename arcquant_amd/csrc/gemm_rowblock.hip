@@ -383,8 +383,14 @@ int gemm_repacked_supported(int64_t M, int64_t N, int64_t K) {
   return rowblock_lds_bytes((int)M, K, 8, &stride) <= 160 * 1024 ? 1 : 0;
 }
 
-// which plain repacked shapes take the no-image kernel (measured on MI355X, tools/decode_stream_bench.py / midm_bench.py)
-static bool rowblock_use_direct(int M, int N, int64_t K) { return false; }
+// Which plain repacked shapes take the no-image kernel (tools/direct_ab.py on MI355X, us per launch image / direct, HBM-cold):
+// M=1 N=K=4096 5.65 / 5.53, M=4 6.10 / 5.74, M=16 7.77 / 6.37, 3584 x 3648 M=4 5.53 / 5.35 -- but 1024 x 4160 4.74 / 4.92 (too few
+// workgroups to hide seven loads per pair) and every large weight loses (14336 x 4160 9.6 / 11.8, 10752 x 3648 8.3 / 10.3,
+// 37888 x 3648 19.6 / 23.9: bandwidth-bound kernels pay for the four extra loads per pair), 3584 x 19008 ties.
+static bool rowblock_use_direct(int M, int N, int64_t K) {
+  const int64_t w = (int64_t)N * K;
+  return w >= ((int64_t)8 << 20) && w <= ((int64_t)24 << 20);
+}
 
 int gemm_repacked(const GemmArgs& a, const uint8_t* RW, const uint8_t* RSF, hipStream_t stream) {
   static const int use_stream = getenv("ARCQ_REPACKED_STREAM") ? atoi(getenv("ARCQ_REPACKED_STREAM")) : 0;   // tuning / A-B only
