@@ -638,12 +638,15 @@ def main():
     flops = gemm_flops(M, N, K)
     # HBM traffic per launch from the committed PMC passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE);
     # bench.py cannot run rocprofv3 on itself, so the number is read from profiles/ and labelled as such
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_tile_gemm.json")) as f:
-            traffic = json.load(f)["per_launch"]["hbm_traffic_bytes"]
-    except Exception:
-        pass
+    traffic, traffic_file = None, None
+    for name in ("r03_pmc_tile_gemm.json", "r02_pmc_tile_gemm.json"):      # the newest committed PMC pass of the shipped kernel
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                traffic = json.load(f)["per_launch"]["hbm_traffic_bytes"]
+            traffic_file = name
+            break
+        except Exception:
+            continue
     value = (1 if strong else world) * flops * args.steps / elapsed / 1e12
     if strong:            # the step's event bracket also holds the all-gather: time this rank's GEMM launch alone for `roofline`
         kern_us = time_events(lambda: agemm.matmul(p["qx"], cp.W, p["sfx"], cp.SFW, p["alpha"]), max(20, args.steps), 5)
@@ -662,7 +665,7 @@ def main():
                                    else f"column-parallel x{world} (no collective)")},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic,
-                     "traffic_source": "profiles/r02_pmc_tile_gemm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)",
+                     "traffic_source": f"profiles/{traffic_file} (rocprofv3 --pmc FETCH_SIZE x 2 [gfx950 correction] + WRITE_SIZE, bytes per launch, separate passes)",
                      "kernel": "arcq::gemm_tile_kernel", "kernel_us": round(kern_us, 2),
                      "frac_of_fp4_peak": round(achieved / PEAK_FP4_TFLOPS, 4),
                      "note": "NVFP4 (ue4m3 scale per 16) has no exact mapping onto gfx950's E8M0-per-32 scaled fp4 MFMA; the exact "
