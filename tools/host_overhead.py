@@ -25,6 +25,17 @@ calls = {
     "matmul (reference layout)": lambda: agemm.matmul(q["qx"], q["qw"], q["sfx"], q["sfw"], q["alpha"]),
     "torch.empty((4, 3584))": lambda: torch.empty((M, N), dtype=torch.bfloat16, device=dev),
 }
+try:                                                           # the pybind11 extension form of the same boundary (csrc/agemm_ext.cpp)
+    from arcquant_amd import _build_ext
+    ext = _build_ext.import_agemm_extension()
+    xs = (q["x"] / q["sx"]).contiguous()
+    calls["EXT matmul (reference layout)"] = lambda: ext.matmul(q["qx"], q["qw"], q["sfx"], q["sfw"], q["alpha"])
+    calls["EXT reorder_quantize_x"] = lambda: ext.reorder_quantize_x(xs, q["idx"], KE)
+    calls["ctypes reorder_quantize_x"] = lambda: agemm.reorder_quantize_x(xs, q["idx"], KE)
+    calls["EXT rmsnorm_quantize_x"] = lambda: ext.rmsnorm_quantize_x(q["x"], wn, 1e-6, q["idx"], KE)
+    calls["ctypes rmsnorm_quantize_x"] = lambda: agemm.rmsnorm_quantize_x(q["x"], wn, 1e-6, q["idx"], KE)
+except ImportError as e:
+    print("extension not built:", e)
 for name, f in calls.items():
     for _ in range(200):
         f()
