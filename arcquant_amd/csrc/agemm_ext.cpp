@@ -11,8 +11,8 @@
 // may be a 0-dim CUDA fp32 tensor and is then read on the device (the reference's `const float scale` forces `.item()`); KQ is not
 // limited to the reference's template list.
 #include <torch/extension.h>
-#include <c10/hip/HIPStream.h>
-#include <c10/hip/HIPGuard.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>      // torch-ROCm tensors say "cuda": the guard / stream types that accept it
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include <stdexcept>
 #include <string>
@@ -33,7 +33,7 @@ void check(int status, const char* what) {
   if (status != ARCQ_OK) throw std::runtime_error(std::string(what) + ": " + arcq_last_error());
 }
 
-void* stream_of(const torch::Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+void* stream_of(const torch::Tensor& t) { return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
 
 // agemm.matmul(A, B, SFA, SFB, scale) -> bf16 [M, N]   (bindings.cpp:99-120)
 torch::Tensor matmul(const torch::Tensor& A, const torch::Tensor& B, const torch::Tensor& SFA, const torch::Tensor& SFB, const py::object& scale) {
@@ -59,7 +59,7 @@ torch::Tensor matmul(const torch::Tensor& A, const torch::Tensor& B, const torch
   } else {
     alpha_host = scale.cast<float>();
   }
-  c10::hip::HIPGuard guard(A.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(A.device());
   auto D = torch::empty({M, N}, A.options().dtype(torch::kBFloat16));
   const int64_t ws_bytes = arcq_gemm_workspace_bytes(M, N, K);
   torch::Tensor ws;
@@ -77,7 +77,7 @@ std::tuple<torch::Tensor, torch::Tensor> quantize(bool is_x, const torch::Tensor
   const int64_t rows = X.size(0), KQ = X.size(1), K = KQ + KE;
   if (reorder_index.numel() != KQ || KQ % 64 || KE % 64 || KE < 0 || KE > KQ)
     throw std::runtime_error(std::string("Value error in ") + who + ": KQ / KE / reorder_index are not valid");       // bindings.cpp:157-160
-  c10::hip::HIPGuard guard(X.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(X.device());
   auto Q = torch::empty({rows, K / 2}, X.options().dtype(torch::kUInt8));
   auto SF = torch::empty({arcq_sf_alloc_bytes(rows, K)}, X.options().dtype(torch::kUInt8));      // bindings.cpp:83-95
   const int variant = arcq_variant_for_kq(KQ);
@@ -102,7 +102,7 @@ std::tuple<torch::Tensor, torch::Tensor> rmsnorm_quantize_x(const torch::Tensor&
   const int64_t M = X.size(0), KQ = X.size(1), K = KQ + KE;
   if (W.numel() != KQ || reorder_index.numel() != KQ || KQ % 64 || KE % 64 || KE < 0 || KE > KQ || KQ < 2048 || KQ > 8192)
     throw std::runtime_error("Value error in run_rmsnorm_x_bf16_nvfp4: K value is not valid: " + std::to_string(KQ));   // bindings.cpp:248-251
-  c10::hip::HIPGuard guard(X.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(X.device());
   auto Q = torch::empty({M, K / 2}, X.options().dtype(torch::kUInt8));
   auto SF = torch::empty({arcq_sf_alloc_bytes(M, K)}, X.options().dtype(torch::kUInt8));
   check(arcq_rmsnorm_quantize_x(X.data_ptr(), W.data_ptr(), (float)eps, reorder_index.data_ptr<int16_t>(), Q.data_ptr<uint8_t>(), SF.data_ptr<uint8_t>(), M, KQ,
