@@ -68,8 +68,10 @@ __device__ __forceinline__ f16x2 sf_pair_at(uint32_t word, uint32_t off) {
 __device__ __forceinline__ Frag8 dequant8(uint32_t codes, f16x2 s2) {
   Frag8 f;
 #ifdef ARCQ_EXPERIMENT_NO_SCALE_MUL
-  // TIMING EXPERIMENT ONLY (tools/scripts/build_variant_lib.sh; results are WRONG): the block-scale multiply dropped -- the upper
-  // bound of what folding the scale into the conversion could gain (profiles/r03_tile_dequant_upper_bound_ab.jsonl)
+  // TIMING EXPERIMENT ONLY (tools/scripts/build_variant_lib.sh; results are WRONG): the block-scale multiply dropped.  +12 % on the
+  // tile GEMM -- but NOT because of the instruction: the operands then carry one significant mantissa bit, the matrix pipe draws less
+  // power and the chip clocks higher.  The instruction-count experiment is ARCQ_EXPERIMENT_A_RAW (gemm_tile_common.hpp): half of
+  // all dequantisation instructions removed at unchanged operand density = +3 % (profiles/r03_tile_dequant_upper_bound_ab.jsonl)
   f.p[0] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(codes, 256.0f, 0);
   f.p[1] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(codes, 256.0f, 1);
   f.p[2] = __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(codes, 256.0f, 2);

@@ -225,7 +225,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
       for (int c = blk; c < kPieces; c += kBlocks) {
         const int u = c >> 2, j = c & 3;
         if (u < A_UNITS) {
+#ifdef ARCQ_EXPERIMENT_A_RAW
+          if (!A_PARTIAL || tid < BM * 2) stage_piece_raw(na, a_slot[u < A_UNITS ? u : 0][j], ta[u < A_UNITS ? u : 0], a_live[u < A_UNITS ? u : 0], j);
+#else
           if (!A_PARTIAL || tid < BM * 2) stage_piece(na, a_slot[u < A_UNITS ? u : 0][j], ta[u < A_UNITS ? u : 0], a_live[u < A_UNITS ? u : 0], j);
+#endif
         } else {
           const int v = u - A_UNITS < B_UNITS ? u - A_UNITS : 0;
           stage_piece(nb, b_slot[v][j], tb[v], b_live[v], j);
