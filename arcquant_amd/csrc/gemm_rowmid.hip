@@ -47,9 +47,13 @@ struct RowmidRegs {       // one tile pair of this lane: 2 x 16 bytes of codes, 
 };
 
 constexpr int kRmWaves = 8, kRmThreads = kRmWaves * 64;
+#ifndef ARCQ_ROWMID_WPS2
+#define ARCQ_ROWMID_WPS2 4      // waves per SIMD asked of the two-token-tile kernels (4 = two workgroups per CU, 128 registers; A-B: 2)
+#endif
 
 template <int kTok>       // token tiles of 16: 2, 3 or 4
-__global__ __launch_bounds__(kRmThreads, 2) void gemm_rowmid_kernel(RowmidParams p) {
+// (second launch bound = waves per SIMD: 4 = two 8-wave workgroups per CU, which the LDS of two token tiles allows; above, one)
+__global__ __launch_bounds__(kRmThreads, kTok <= 2 ? ARCQ_ROWMID_WPS2 : 2) void gemm_rowmid_kernel(RowmidParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const a_lds = smem;                                         // [M][a_stride] packed codes, K padded with zeros
   unsigned char* const s_lds = smem + p.sf_off;                              // [M][s_stride] ue4m3 bytes, natural order
@@ -183,6 +187,147 @@ __global__ __launch_bounds__(kRmThreads, 2) void gemm_rowmid_kernel(RowmidParams
   }
 }
 
+// ---- the same contraction with NO activations in LDS ("rowtok"): every lane fetches the MFMA B operands of its token tiles itself,
+// per tile pair, from the packed activations in global memory (a few hundred KB that every workgroup reads: L2 / L1 hits) -- the
+// no-image kernel of gemm_rowblock.hip generalised to kTok token tiles.  No LDS fill (the 74 KB every workgroup copies at M = 32),
+// no barrier before the K loop, and no LDS capacity limit: it reaches M = 128.  Costs kTok x 4 loads per tile pair beside the 3
+// weight loads; the weight ring stays three pairs deep, the activation loads of a pair are issued when its step starts (their
+// latency is hidden by the other waves of the CU, not by a ring: kTok x 10 registers per pair).
+template <int kTok>
+__global__ __launch_bounds__(kRmThreads, kTok <= 2 ? 4 : 2) void gemm_rowtok_kernel(RowmidParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* const red = reinterpret_cast<float*>(smem);    // [8 waves][kTok][64][4] when slices > 1
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, rl = lane & 15;
+  const int bpw = kRmWaves / p.slices;
+  const int rb = blockIdx.x * bpw + wave / p.slices;
+  const int slice = wave % p.slices;
+  const bool active = rb < p.row_blocks;
+  int pr_begin, pr_count;
+  rowblock_slice_range(p.pairs, p.slices, slice, &pr_begin, &pr_count);
+  const int npairs = active ? pr_count : 0;
+  const float alpha = p.alpha_host * (p.alpha_dev ? *p.alpha_dev : 1.0f);
+
+  const int rbc = active ? rb : 0;
+  const int pr_load = rowblock_load_base(pr_begin, npairs);
+  const uint8_t* wp = p.RW + ((size_t)rbc * p.pairs + pr_load) * 2048 + lane * 16;
+  const uint8_t* sp = p.RSF + ((size_t)rbc * p.pairs + pr_load) * 256 + lane * 4;
+  const int last = npairs > 0 ? npairs - 1 : 0;
+  int issued = 0;
+  auto issue = [&](RowmidRegs& r) __attribute__((always_inline)) {
+    const int i = min(issued, last);
+    r.b0 = ARCQ_WLOAD(reinterpret_cast<const rm_u32x4*>(wp + (size_t)i * 2048));
+    r.b1 = ARCQ_WLOAD(reinterpret_cast<const rm_u32x4*>(wp + (size_t)i * 2048 + 1024));
+    r.s = ARCQ_WLOAD(reinterpret_cast<const uint32_t*>(sp + (size_t)i * 256));
+    ++issued;
+  };
+  // activation rows of this lane (tokens >= M: the last row, never stored) and the clamps for tiles / atoms past K (they meet zero
+  // weight scales; gemm_rowblock.hip, direct kernel)
+  const int atoms_k = p.K >> 6, tiles_k = p.K >> 7, halfk = (p.K & 64) ? 1 : 0;
+  const uint8_t* arow[kTok];
+  const uint8_t* srow[kTok];
+#pragma unroll
+  for (int t = 0; t < kTok; ++t) {
+    const int tok = min(t * 16 + rl, p.M - 1);
+    arow[t] = p.A + (size_t)tok * (p.K >> 1) + q * 16;
+    srow[t] = p.SFA + sf_atom_offset(tok, 0, atoms_k) + (q & 1) * 2;
+  }
+  auto a_off = [&](int t) __attribute__((always_inline)) -> size_t {
+    const int tc = min(t, tiles_k - 1 + halfk);
+    size_t off = (size_t)tc * 64;
+    if (halfk && tc == tiles_k && q >= 2) off -= 32;         // second half of a trailing half tile: quarters q - 2 (zero weight scales there)
+    return off;
+  };
+  auto s_off = [&](int t) __attribute__((always_inline)) -> size_t { return (size_t)min(2 * t + (q >> 1), atoms_k - 1) * 512; };
+
+  RowmidRegs r0, r1, r2;
+  issue(r0);
+  issue(r1);
+  issue(r2);
+
+  f32x4 acc[kTok];
+#pragma unroll
+  for (int t = 0; t < kTok; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int done = 0;
+  auto step = [&](RowmidRegs& r) __attribute__((always_inline)) {
+    const int t0 = 2 * (pr_begin + done), t1 = t0 + 1;
+    const size_t oa0 = a_off(t0), oa1 = a_off(t1), os0 = s_off(t0), os1 = s_off(t1);
+    rm_u32x4 xa0[kTok], xa1[kTok];
+    uint32_t xs0[kTok], xs1[kTok];
+#pragma unroll
+    for (int t = 0; t < kTok; ++t) {                         // every activation load of the pair first ...
+      xa0[t] = *reinterpret_cast<const rm_u32x4*>(arow[t] + oa0);
+      xa1[t] = *reinterpret_cast<const rm_u32x4*>(arow[t] + oa1);
+      xs0[t] = *reinterpret_cast<const uint16_t*>(srow[t] + os0);
+      xs1[t] = *reinterpret_cast<const uint16_t*>(srow[t] + os1);
+    }
+    {                                                        // ... then the pair's two tiles against every token tile
+      const f16x2 s0 = sf_pair_at(r.s, 0), s1 = sf_pair_at(r.s, 8);
+      const Frag8 b0 = dequant8(r.b0.x, s0), b1 = dequant8(r.b0.y, s0), b2 = dequant8(r.b0.z, s1), b3 = dequant8(r.b0.w, s1);
+#pragma unroll
+      for (int t = 0; t < kTok; ++t) {
+        const f16x2 u0 = sf_pair_at(xs0[t], 0), u1 = sf_pair_at(xs0[t], 8);
+        const Frag8 a0 = dequant8(xa0[t].x, u0), a1 = dequant8(xa0[t].y, u0), a2 = dequant8(xa0[t].z, u1), a3 = dequant8(xa0[t].w, u1);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0.v, a0.v, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1.v, a1.v, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b2.v, a2.v, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b3.v, a3.v, acc[t], 0, 0, 0);
+      }
+    }
+    {
+      const f16x2 s0 = sf_pair_at(r.s >> 16, 0), s1 = sf_pair_at(r.s >> 16, 8);
+      const Frag8 b0 = dequant8(r.b1.x, s0), b1 = dequant8(r.b1.y, s0), b2 = dequant8(r.b1.z, s1), b3 = dequant8(r.b1.w, s1);
+#pragma unroll
+      for (int t = 0; t < kTok; ++t) {
+        const f16x2 u0 = sf_pair_at(xs1[t], 0), u1 = sf_pair_at(xs1[t], 8);
+        const Frag8 a0 = dequant8(xa1[t].x, u0), a1 = dequant8(xa1[t].y, u0), a2 = dequant8(xa1[t].z, u1), a3 = dequant8(xa1[t].w, u1);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0.v, a0.v, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1.v, a1.v, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b2.v, a2.v, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b3.v, a3.v, acc[t], 0, 0, 0);
+      }
+    }
+    issue(r);                                               // refill: three pairs ahead
+    __builtin_amdgcn_sched_barrier(0);
+    ++done;
+  };
+#pragma unroll 1
+  while (done + 3 <= npairs) {
+    step(r0);
+    step(r1);
+    step(r2);
+  }
+  if (done < npairs) step(r0);
+  if (done < npairs) step(r1);
+
+  if (p.slices > 1) {
+#pragma unroll
+    for (int t = 0; t < kTok; ++t)
+      *reinterpret_cast<float4*>(red + ((wave * kTok + t) * 64 + lane) * 4) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+    __syncthreads();
+    if (slice != 0) return;
+    for (int s2 = 1; s2 < p.slices; ++s2) {
+#pragma unroll
+      for (int t = 0; t < kTok; ++t) {
+        const float4 v = *reinterpret_cast<const float4*>(red + (((wave + s2) * kTok + t) * 64 + lane) * 4);
+        acc[t][0] += v.x; acc[t][1] += v.y; acc[t][2] += v.z; acc[t][3] += v.w;
+      }
+    }
+  }
+  const int n0 = rb * 16 + 4 * q;
+  if (active && n0 < p.N) {
+#pragma unroll
+    for (int t = 0; t < kTok; ++t) {
+      const int m = t * 16 + rl;
+      if (m < p.M) {
+        const float sum[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
+        finish4<uint32_t>(p, alpha, m, n0, sum);
+      }
+    }
+  }
+}
+
 static int64_t rowmid_pairs(int64_t K) { return (K + 255) / 256; }
 
 static int rowmid_lds_bytes(int M, int64_t K, int slices, int tok, RowmidParams* p) {
@@ -199,8 +344,22 @@ static int rowmid_lds_bytes(int M, int64_t K, int slices, int tok, RowmidParams*
 
 // 1 = this shape runs on the mid-M repacked path: 16 < M <= 64 and the packed activations fit one workgroup's LDS twice per CU
 // is NOT required -- one workgroup per CU is enough to stream (the launcher asks for what fits)
+// ARCQ_ROWTOK (tuning / A-B): 0 = never the no-LDS kernel, 1 = always (where it applies: 16 < M <= 128), unset = by shape
+static int rowtok_env() {
+  static const int v = getenv("ARCQ_ROWTOK") ? atoi(getenv("ARCQ_ROWTOK")) : -1;
+  return v;
+}
+static bool rowtok_preferred(int64_t M, int64_t N, int64_t K) {
+  if (M <= 16 || M > 128) return false;
+  const int e = rowtok_env();
+  if (e >= 0) return e != 0;
+  return false;
+}
+
 int gemm_repacked_mid_supported(int64_t M, int64_t N, int64_t K) {
-  if (M <= 16 || M > 64 || N < 1 || K < 64 || (K % 64)) return 0;
+  if (N < 1 || K < 64 || (K % 64)) return 0;
+  if (rowtok_preferred(M, N, K)) return 1;
+  if (M <= 16 || M > 64) return 0;
   // three and four token tiles per weight unit are compute-bound (activation conversions + MFMA per unit); on large weights the
   // LDS-tiled GEMM with its 64 x 256 tiles catches up: N = 37888, K = 3648: M = 48 53.7 vs 53.7 us, M = 64 67.0 vs 58.1 us
   // (tools/midm_bench.py), while N = 10752 still gains at M = 64 (23.9 vs 26.6 us)
@@ -212,6 +371,7 @@ int gemm_repacked_mid(const GemmArgs& a, const uint8_t* RW, const uint8_t* RSF, 
   if (a.epilogue != kEpiPlain) return fail(ARCQ_ERR_UNSUPPORTED, "arcq_gemm_nvfp4_repacked: M=%d > 16 has no SiLU epilogue", a.M);
   if (!gemm_repacked_mid_supported(a.M, a.N, a.K))
     return fail(ARCQ_ERR_UNSUPPORTED, "arcq_gemm_nvfp4_repacked: M=%d K=%d outside the repacked path (M <= 64, packed activations <= 160 KB)", a.M, a.K);
+  const bool tokk = rowtok_preferred(a.M, a.N, a.K);
   RowmidParams p;
   p.A = a.A; p.SFA = a.SFA; p.RW = RW; p.RSF = RSF; p.D = a.D;
   p.alpha_dev = a.alpha_dev; p.bias = a.bias; p.residual = a.residual;
@@ -224,6 +384,31 @@ int gemm_repacked_mid(const GemmArgs& a, const uint8_t* RW, const uint8_t* RSF, 
   if (s > p.pairs) s = 1;
   p.slices = s;
   const int tok = (a.M + 15) / 16;
+  if (tokk) {                                               // no activations in LDS: only the slice reduction's scratch
+    const int ktok = tok <= 4 ? tok : (tok <= 6 ? 6 : 8);
+    const int tlds = s > 1 ? kRmWaves * ktok * 64 * 4 * (int)sizeof(float) : 0;
+    const int tbpw = kRmWaves / s;
+    const int tgrid = (p.row_blocks + tbpw - 1) / tbpw;
+    p.a_stride = p.s_stride = p.sf_off = 0;
+    static LdsOptIn tok_lds[5];
+    auto tlaunch = [&](auto kernel, LdsOptIn* opt) -> int {
+      if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), *opt, tlds, "arcq_gemm_nvfp4_repacked")) return rc;
+      hipLaunchKernelGGL(kernel, dim3((unsigned)tgrid), dim3(kRmThreads), tlds, stream, p);
+      return ARCQ_OK;
+    };
+    int rc;
+    switch (ktok) {
+      case 2: rc = tlaunch(gemm_rowtok_kernel<2>, &tok_lds[0]); break;
+      case 3: rc = tlaunch(gemm_rowtok_kernel<3>, &tok_lds[1]); break;
+      case 4: rc = tlaunch(gemm_rowtok_kernel<4>, &tok_lds[2]); break;
+      case 6: rc = tlaunch(gemm_rowtok_kernel<6>, &tok_lds[3]); break;
+      default: rc = tlaunch(gemm_rowtok_kernel<8>, &tok_lds[4]); break;
+    }
+    if (rc != ARCQ_OK) return rc;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ARCQ_ERR_LAUNCH, "arcq_gemm_nvfp4_repacked: launch failed: %s", hipGetErrorString(e));
+    return ARCQ_OK;
+  }
   const int lds = rowmid_lds_bytes(a.M, a.K, s, tok, &p);
   const int bpw = kRmWaves / s;
   const int grid = (p.row_blocks + bpw - 1) / bpw;

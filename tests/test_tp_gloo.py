@@ -222,3 +222,45 @@ def test_column_to_row_handoff_both_ways_against_the_unsharded_oracle(tmp_path, 
     assert err_a < 0.2 and err_b < 0.2 and abs(err_a - err_b) < 0.02, (err_a, err_b)
     assert tp.handoff_bytes_per_rank(M, NI, world, "gather") == (world - 1) * M * (NI // world) * 2
     assert tp.handoff_bytes_per_rank(M, NI, world, "local_scale") == 4 * (world - 1)
+
+
+# ---------------------------------------------------------------------------- sharded linears WITH a bias
+def _bias_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests import oracle_ops as OPS
+        M, N, K, qx, sfx, qw, sfw, alpha = _problem()
+        g = torch.Generator().manual_seed(99)
+        bias = (torch.randn(N, generator=g) * 4).to(torch.bfloat16)
+        res = (torch.randn(M, N, generator=g) * 4).to(torch.bfloat16)
+        QX, SFX, QW, SFW = (torch.from_numpy(a) for a in (qx, sfx, qw, sfw))
+        col = tp.ColumnParallelARCLinear(QW, SFW, 1.0, rank, world, bias=bias, ops=OPS)
+        y_col = col.forward(QX, SFX, alpha, gather_output=True)
+        row = tp.RowParallelARCLinear(QW, SFW, 1.0, rank, world, bias=bias, ops=OPS)
+        y_row = row.forward(QX, SFX, alpha, residual=res)
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "bias.npz"), col=bits(y_col), row=bits(y_row))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_linears_with_bias_round_like_the_unsharded_layer(tmp_path, world):
+    """Column-parallel: the bias rides in each shard's GEMM epilogue; row-parallel: it is added AFTER the reduction, with the
+    single-GPU epilogue's roundings bf16(bf16(sum) + bias), then bf16(residual + y) (model/qLinearLayer.py:74-76)."""
+    mp.spawn(_bias_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    M, N, K, qx, sfx, qw, sfw, alpha = _problem()
+    g = torch.Generator().manual_seed(99)
+    bias = (torch.randn(N, generator=g) * 4).to(torch.bfloat16)
+    res = (torch.randn(M, N, generator=g) * 4).to(torch.bfloat16)
+    yb, _ = O.gemm(qx, qw, sfx, sfw, alpha)
+    y = torch.from_numpy(yb.view(np.int16)).view(torch.bfloat16)
+    want_col = y + bias
+    want_row = res + (y + bias)
+    got = np.load(os.path.join(str(tmp_path), "bias.npz"))
+    assert np.array_equal(got["col"], bits(want_col))                      # same products per column, same epilogue: bit-exact
+    d = np.abs(got["row"].astype(np.int32) - bits(want_row).astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 0.01                           # fp32 partials of the K slices: at most a rounding-boundary flip
