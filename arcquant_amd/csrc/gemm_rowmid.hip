@@ -344,34 +344,40 @@ static int rowmid_lds_bytes(int M, int64_t K, int slices, int tok, RowmidParams*
 
 // 1 = this shape runs on the mid-M repacked path: 16 < M <= 64 and the packed activations fit one workgroup's LDS twice per CU
 // is NOT required -- one workgroup per CU is enough to stream (the launcher asks for what fits)
-// ARCQ_ROWTOK (tuning / A-B): 0 = never the no-LDS kernel, 1 = always (where it applies: 16 < M <= 128), unset = by shape
-static int rowtok_env() {
+// ---- which kernel for a decode batch (16 < M <= 128)?  Measured on MI355X (tools/rowtok_ab.py, profiles/r03_decode_batch_kernels_ab.jsonl;
+// HBM-cold, us: LDS-resident packed activations | no LDS | tiled GEMM + finish pass):
+//   4096 x 4096    M = 32  8.9 |  7.5 | 16.7    M = 64 13.5 | 10.9 | 21.3    M = 128    - | 19.2 | 23.2
+//   3584 x 3648    M = 32  8.7 |  6.5 | 19.7    M = 64 13.2 |  8.8 | 24.5    M = 128    - | 14.8 | 21.6
+//   10752 x 3648   M = 32 15.1 | 16.4 | 21.4    M = 64 23.9 | 24.7 | 26.6    M = 128    - | 41.7 | 30.4
+//   37888 x 3648   M = 32 34.7 | 40.1 | 49.4    M = 64 67.0 | 68.7 | 58.0
+//   3584 x 19008   M = 32    - | 21.1 | 31.3    (the packed activations of 32 tokens x 19008 do not fit LDS)
+// Small weights are latency chains: no LDS fill, no barrier wins at every M.  Large weights are compute-bound per token tile: LDS operands
+// (one ds_read_b128 instead of a global load per tile) win while they fit, then the tiled GEMM.
+enum : int { kMidNone = 0, kMidLds = 1, kMidTok = 2 };
+static int rowtok_env() {       // ARCQ_ROWTOK (tuning / A-B): 0 = never the no-LDS kernel, 1 = always (16 < M <= 128), unset = by shape
   static const int v = getenv("ARCQ_ROWTOK") ? atoi(getenv("ARCQ_ROWTOK")) : -1;
   return v;
 }
-static bool rowtok_preferred(int64_t M, int64_t N, int64_t K) {
-  if (M <= 16 || M > 128) return false;
+static int mid_kind(int64_t M, int64_t N, int64_t K) {
+  if (M <= 16 || M > 128 || N < 1 || K < 64 || (K % 64)) return kMidNone;
+  const bool lds_fits = M <= 64 && rowmid_lds_bytes((int)M, K, 8, (int)((M + 15) / 16), nullptr) <= 160 * 1024;
   const int e = rowtok_env();
-  if (e >= 0) return e != 0;
-  return false;
+  if (e == 1) return kMidTok;
+  const int64_t w = N * K;
+  if (e != 0 && w <= ((int64_t)32 << 20)) return kMidTok;                 // small weights: every M up to 128
+  if (M <= 32) return lds_fits ? kMidLds : (e != 0 ? kMidTok : kMidNone);
+  if (M <= 64 && w <= ((int64_t)64 << 20) && lds_fits) return kMidLds;
+  return kMidNone;                                                          // the tiled GEMM (arcq_gemm_nvfp4) is faster
 }
 
-int gemm_repacked_mid_supported(int64_t M, int64_t N, int64_t K) {
-  if (N < 1 || K < 64 || (K % 64)) return 0;
-  if (rowtok_preferred(M, N, K)) return 1;
-  if (M <= 16 || M > 64) return 0;
-  // three and four token tiles per weight unit are compute-bound (activation conversions + MFMA per unit); on large weights the
-  // LDS-tiled GEMM with its 64 x 256 tiles catches up: N = 37888, K = 3648: M = 48 53.7 vs 53.7 us, M = 64 67.0 vs 58.1 us
-  // (tools/midm_bench.py), while N = 10752 still gains at M = 64 (23.9 vs 26.6 us)
-  if (M > 32 && N * K > (int64_t)64 << 20) return 0;
-  return rowmid_lds_bytes((int)M, K, 8, (int)((M + 15) / 16), nullptr) <= 160 * 1024 ? 1 : 0;
-}
+int gemm_repacked_mid_supported(int64_t M, int64_t N, int64_t K) { return mid_kind(M, N, K) != kMidNone ? 1 : 0; }
 
 int gemm_repacked_mid(const GemmArgs& a, const uint8_t* RW, const uint8_t* RSF, hipStream_t stream) {
   if (a.epilogue != kEpiPlain) return fail(ARCQ_ERR_UNSUPPORTED, "arcq_gemm_nvfp4_repacked: M=%d > 16 has no SiLU epilogue", a.M);
-  if (!gemm_repacked_mid_supported(a.M, a.N, a.K))
-    return fail(ARCQ_ERR_UNSUPPORTED, "arcq_gemm_nvfp4_repacked: M=%d K=%d outside the repacked path (M <= 64, packed activations <= 160 KB)", a.M, a.K);
-  const bool tokk = rowtok_preferred(a.M, a.N, a.K);
+  const int kind = mid_kind(a.M, a.N, a.K);
+  if (kind == kMidNone)
+    return fail(ARCQ_ERR_UNSUPPORTED, "arcq_gemm_nvfp4_repacked: M=%d N=%d K=%d outside the repacked path (see arcq_gemm_repacked_supported)", a.M, a.N, a.K);
+  const bool tokk = kind == kMidTok;
   RowmidParams p;
   p.A = a.A; p.SFA = a.SFA; p.RW = RW; p.RSF = RSF; p.D = a.D;
   p.alpha_dev = a.alpha_dev; p.bias = a.bias; p.residual = a.residual;

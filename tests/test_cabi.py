@@ -100,16 +100,18 @@ def test_round2_entry_points_reject_bad_arguments_without_a_gpu():
     assert silu(P, P, 1e-6, P, P, P, P, P, 4, 3586, 3584, 64, 1, 1.0, None, None, None, None) == -1 and b"N % 4" in L.arcq_last_error()
     assert silu(P, P, 1e-6, P, P, P, P, P, 4, 3584, 3584, 64, 1, 1.0, None, None, P + 2, None) == -1    # act_scatter_index alignment
     assert L.arcq_linear_dynamic_repacked(P, P, P, P, P, None, None, 0, 4, 3584, 3584, 100, 1, 1.0, None, None, 0, None) == -1
-    for fn, m_unsupported in ((L.arcq_gemm_nvfp4_repacked, 65), (L.arcq_gemm_nvfp4_repacked_stream, 17)):
+    for fn, m_unsupported in ((L.arcq_gemm_nvfp4_repacked, 129), (L.arcq_gemm_nvfp4_repacked_stream, 17)):
         assert fn(P, P, P, P, P, m_unsupported, 4096, 4160, 1.0, None, None, None, 0, None) == -2
         # bias / residual are fetched 8 bytes at a time when N % 4 == 0
         assert fn(P, P, P, P, P, 4, 4096, 4160, 1.0, None, P + 2, None, 0, None) == -1 and b"8-byte" in L.arcq_last_error()
         assert fn(P, P, P, P, P, 4, 4096, 4160, 1.0, None, None, P + 4, 0, None) == -1 and b"8-byte" in L.arcq_last_error()
-    # decode batches (16 < M <= 64) take the repacked path while the packed activations fit LDS and the weight is not so large that
-    # the tiled GEMM wins (gemm_rowmid.hip)
-    assert L.arcq_gemm_repacked_supported(17, 4096, 4160) == 1 and L.arcq_gemm_repacked_supported(64, 4096, 4160) == 1
+    # decode batches (16 < M <= 128) take the repacked path where it beats the tiled GEMM (gemm_rowmid.hip, mid_kind): small weights at
+    # every M, large ones up to M = 32 (64 while the packed activations fit LDS and the weight is < 64 M elements)
+    assert L.arcq_gemm_repacked_supported(17, 4096, 4160) == 1 and L.arcq_gemm_repacked_supported(128, 4096, 4160) == 1
     assert L.arcq_gemm_repacked_supported(64, 37888, 3648) == 0 and L.arcq_gemm_repacked_supported(32, 37888, 3648) == 1
-    assert L.arcq_gemm_repacked_supported(32, 4096, 14400) == 0 and L.arcq_gemm_repacked_supported(65, 256, 256) == 0
+    assert L.arcq_gemm_repacked_supported(32, 3584, 19008) == 1 and L.arcq_gemm_repacked_supported(64, 3584, 19008) == 0
+    assert L.arcq_gemm_repacked_supported(64, 10752, 3648) == 1 and L.arcq_gemm_repacked_supported(128, 10752, 3648) == 0
+    assert L.arcq_gemm_repacked_supported(129, 256, 256) == 0
     assert lin(P, P, 1e-6, P, P, P, P, 4, 3584, 3584, 64, 1, 1.0, None, P + 2, None, 0, None) == -1 and b"8-byte" in L.arcq_last_error()
     # harness (include/arcq_harness.h)
     assert L.arcq_harness_attn_decode_window(P, P, P, P, P, 4, 28, 1152, 10, 11, None) == -1             # first > pos

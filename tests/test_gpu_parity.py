@@ -491,9 +491,12 @@ def test_repacked_weight_gemm_equals_the_reference_layout_gemm():
     cases = [(1, 512, 256, 64, O.G16), (4, 100, 256, 64, O.G16), (3, 1000, 64, 0, O.G16), (16, 272, 1024, 64, O.G16),
              (8, 777, 512, 64, O.G16), (4, 3584, 3584, 64, O.G32), (2, 52000, 256, 64, O.G16), (5, 5120, 384, 0, O.G16),
              (4, 256, 18944, 64, O.G32),        # a 153.7 KB activation image (Qwen2.5-7B down-projection at bs=4)
-             # decode batches, 16 < M <= 64: the weight is still read once, activations stay packed in LDS (gemm_rowmid.hip)
+             # decode batches, 16 < M <= 128: the weight is still read once; activations fetched per tile pair (no LDS: small weights, any
+             # K) or resident packed in LDS (large weights while they fit) -- gemm_rowmid.hip, mid_kind
              (17, 128, 256, 64, O.G16), (32, 1000, 2048, 64, O.G16), (33, 516, 2048, 0, O.G16), (48, 777, 512, 64, O.G16),
-             (64, 272, 1024, 64, O.G16), (40, 3584, 3584, 64, O.G32), (64, 4096, 4096, 64, O.G16), (32, 4096, 4096, 0, O.G16)]
+             (64, 272, 1024, 64, O.G16), (40, 3584, 3584, 64, O.G32), (64, 4096, 4096, 64, O.G16), (32, 4096, 4096, 0, O.G16),
+             (96, 520, 1088, 64, O.G16), (128, 4096, 4096, 64, O.G16), (100, 3584, 3584, 64, O.G32), (81, 1000, 64, 0, O.G16),
+             (32, 256, 18944, 64, O.G32), (32, 10752, 3584, 64, O.G32), (64, 10752, 3584, 64, O.G32), (32, 37888, 3584, 64, O.G32)]
     for (M, N, KQ, KE, variant) in cases:
         K = KQ + KE
         assert ag.repacked_supported(M, N, K)
@@ -515,7 +518,7 @@ def test_repacked_weight_gemm_equals_the_reference_layout_gemm():
         want16 = res + (got32.to(torch.bfloat16) + bias)          # the reference's op order: matmul -> + bias -> x + y, each in bf16
         got16 = ag.matmul_repacked(A, RW, SFA, RSF, dev_scale, N, scale_host=0.5, bias=bias, residual=res)
         assert torch.equal(got16, want16), (M, N, K)
-    assert not ag.repacked_supported(65, 256, 256) and not ag.repacked_supported(5, 256, 19008) and not ag.repacked_supported(32, 256, 14400)
+    assert not ag.repacked_supported(129, 256, 256) and not ag.repacked_supported(5, 256, 19008) and not ag.repacked_supported(64, 37888, 3648)
     with pytest.raises(RuntimeError):
         ag.matmul_repacked(A, RW[:-1], SFA, RSF, alpha, N)
 
