@@ -158,15 +158,16 @@ int arcq_quantize_x_dyn_slots(const void *X, const int16_t *reorder_index, uint8
                               const uint32_t *absmax_slots, int64_t nslots, int64_t M, int64_t KQ, int64_t KE,
                               int variant, void *stream);
 
-/* ---- decode GEMM over a REPACKED weight (optional fast path for M <= 16) ----------------------------------------
+/* ---- decode GEMM over a REPACKED weight (optional fast path for M <= 128) ---------------------------------------
  * A static weight can be laid out for the hardware once: RW = tiles of 16 rows x 128 K elements (1 KB) in MFMA operand
  * order (lane 16*q + r of a wave holds the 16 bytes of row r, K elements [32q, 32q+32) of the tile; the tiles of a row
  * block are consecutive), RSF = per pair of tiles 256 bytes, lane l holding the ue4m3 bytes of its two groups in the
  * first and in the second tile; K padded to a multiple of 256 and N to a multiple of 16 with zero scales.  Sizes from
  * arcq_repacked_{w,sf}_bytes; arcquant_amd/agemm.py:repack_w builds both from the reference layout (pure data movement,
  * nothing is re-quantised).  A / SFA stay in the reference layout.  arcq_gemm_repacked_supported tells whether a shape
- * can take this path (M <= 16 and the fp16 image of the activations fits LDS); results equal arcq_gemm_nvfp4's up to
- * fp32 accumulation order. */
+ * can take this path -- M <= 16 and the fp16 image of the activations fits LDS, or a decode batch 16 < M <= 128 on a
+ * weight where reading it once beats the tiled GEMM (activations fetched per tile pair or kept packed in LDS; gemm_rowmid.hip) --;
+ * results equal arcq_gemm_nvfp4's up to fp32 accumulation order. */
 int64_t arcq_repacked_w_bytes(int64_t N, int64_t K);
 int64_t arcq_repacked_sf_bytes(int64_t N, int64_t K);
 int arcq_gemm_repacked_supported(int64_t M, int64_t N, int64_t K);
