@@ -6,6 +6,8 @@ of the fp64 oracle and bf16 output within one bf16 ulp of the oracle's rounding.
 """
 import ctypes
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -499,7 +501,9 @@ def test_repacked_weight_gemm_equals_the_reference_layout_gemm():
              (32, 256, 18944, 64, O.G32), (32, 10752, 3584, 64, O.G32), (64, 10752, 3584, 64, O.G32), (32, 37888, 3584, 64, O.G32)]
     for (M, N, KQ, KE, variant) in cases:
         K = KQ + KE
-        assert ag.repacked_supported(M, N, K)
+        if not ag.repacked_supported(M, N, K):             # only under the tuning override that switches the no-LDS kernel off
+            assert M > 16 and os.environ.get("ARCQ_ROWTOK") == "0", (M, N, K)
+            continue
         qx, sfx, qw, sfw, alpha = _make_operands(M, N, KQ, KE, variant, 77 + M + N)
         A, B = torch.from_numpy(qx).to(DEV), torch.from_numpy(qw).to(DEV)
         SFA, SFB = torch.from_numpy(sfx).to(DEV), torch.from_numpy(sfw).to(DEV)
@@ -518,7 +522,9 @@ def test_repacked_weight_gemm_equals_the_reference_layout_gemm():
         want16 = res + (got32.to(torch.bfloat16) + bias)          # the reference's op order: matmul -> + bias -> x + y, each in bf16
         got16 = ag.matmul_repacked(A, RW, SFA, RSF, dev_scale, N, scale_host=0.5, bias=bias, residual=res)
         assert torch.equal(got16, want16), (M, N, K)
-    assert not ag.repacked_supported(129, 256, 256) and not ag.repacked_supported(5, 256, 19008) and not ag.repacked_supported(64, 37888, 3648)
+    assert not ag.repacked_supported(129, 256, 256) and not ag.repacked_supported(5, 256, 19008)
+    if "ARCQ_ROWTOK" not in os.environ:      # (the tuning override forces the no-LDS kernel onto every decode batch)
+        assert not ag.repacked_supported(64, 37888, 3648)
     with pytest.raises(RuntimeError):
         ag.matmul_repacked(A, RW[:-1], SFA, RSF, alpha, N)
 
