@@ -39,6 +39,8 @@ echo "pmc decode done"
 ARCQ_HIP_LIB=arcquant_amd/lib/libarcq_hip_diag.so python tools/stream_stamps.py > gpurun_out/${tag}_stream_kernel_stamps.txt 2>&1
 python tools/midm_bench.py > gpurun_out/${tag}_decode_batch_sweep.jsonl 2> gpurun_out/${tag}_midm.err
 python tools/mall_probe.py > gpurun_out/${tag}_weights_hbm_cold_vs_cache_hot.jsonl 2> gpurun_out/${tag}_mall.err
+python tools/e2e_models.py > gpurun_out/${tag}_e2e_other_models.jsonl 2> gpurun_out/${tag}_e2e_models.err
+python tools/direct_ab.py > gpurun_out/${tag}_rowblock_direct_vs_image_ab.jsonl 2> gpurun_out/${tag}_direct_ab.err
 echo "stamps / sweeps done"
 # the multi-GPU paths on this ONE-GPU box: both ranks on cuda:0, gloo instead of RCCL (tests/test_bench_launch_gpu.py runs the same)
 ARCQ_BENCH_ONE_DEVICE=1 ARCQ_BENCH_BACKEND=gloo python bench.py --gpus 2 --no-cpu > gpurun_out/${tag}_bench_gpus2_one_device_gloo.json 2> gpurun_out/${tag}_bench_gpus2.err
