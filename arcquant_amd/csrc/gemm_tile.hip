@@ -232,7 +232,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
 #endif
         } else {
           const int v = u - A_UNITS < B_UNITS ? u - A_UNITS : 0;
+#ifdef ARCQ_EXPERIMENT_B_RAW
+          stage_piece_raw(nb, b_slot[v][j], tb[v], b_live[v], j);
+#else
           stage_piece(nb, b_slot[v][j], tb[v], b_live[v], j);
+#endif
         }
       }
     };

@@ -72,11 +72,11 @@ __device__ __forceinline__ void stage_piece(unsigned char* tile, int slot, const
   *reinterpret_cast<uint4*>(tile + slot) = f.u;
 }
 
-#ifdef ARCQ_EXPERIMENT_A_RAW
+#if defined(ARCQ_EXPERIMENT_A_RAW) || defined(ARCQ_EXPERIMENT_B_RAW)
 // TIMING EXPERIMENT ONLY (tools/scripts/build_variant_lib.sh; results are WRONG): the A panel (activations) staged WITHOUT its
 // dequantisation -- what a tile GEMM reading pre-dequantised fp16 activations (emitted by the quantiser) could gain at most
 __device__ __forceinline__ void stage_piece_raw(unsigned char* tile, int slot, const Staged& s, uint32_t live_mask, int j) {
-  const uint32_t w = (j == 0 ? s.q.x : j == 1 ? s.q.y : j == 2 ? s.q.z : s.q.w) & (live_mask | (live_mask << 16));
+  const uint32_t w = (j == 0 ? s.q.x : j == 1 ? s.q.y : j == 2 ? s.q.z : s.q.w) & (live_mask | (live_mask << 16)) & 0x3bff3bffu;   // finite fp16 patterns
   *reinterpret_cast<uint4*>(tile + slot) = make_uint4(w, w, w, w);
 }
 #endif

@@ -9,6 +9,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHAPES = [(m, 4096, 4096) for m in (128, 256, 512, 1024, 2048, 4096)] + [(m, 3584, 3584) for m in (1024, 2048, 4096)] + [(2048, 10752, 3584), (1024, 37888, 3584)]
+if os.environ.get("SWEEP_SHAPES") == "big":
+    SHAPES = [(4096, 4096, 4096), (8192, 8192, 8192), (4096, 3584, 18944), (4096, 10752, 3584)]
 
 
 def child():
@@ -33,7 +35,7 @@ if __name__ == "__main__":
         child()
         sys.exit(0)
     res = {}
-    for cfg in ("0", "1", "3", "4", "7"):
+    for cfg in os.environ.get("SWEEP_CFGS", "0,1,3,4,7").split(","):
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=dict(os.environ, ARCQ_TILE_CFG=cfg), capture_output=True, text=True)
         for line in r.stdout.splitlines():
             if line.startswith("{"):
