@@ -54,7 +54,7 @@ round (`roofline.frac` 0.548–0.553), the library GEMM beside it 1436–1447:
 |---|---|
 | headline: ARC-NVFP4 GEMM M=N=KQ=4096, KE=64 | **{d['value']:.0f} TFLOP/s**, {d['roofline']['kernel_us']:.1f} µs per launch, `roofline.frac` **{d['roofline']['frac']:.3f}** of the 2.5 PFLOP/s fp16 roof ({d['roofline']['frac_of_fp4_peak']:.3f} of the fp4 roof) |
 | same launch under rocprofv3 | the 200 timed dispatches average {m.group(1)} µs in the kernel trace against {prof['roofline']['kernel_us']:.2f} µs from that run's own events |
-| fp16 library GEMM, same shape, same state | {e['gemm_4096']['fp16_rocblas_TFLOPs']:.0f} TFLOP/s (ours {e['gemm_4096']['speedup_vs_fp16_rocblas']:.3f}×); 8192²: ours {e['gemm_8192']['TFLOPs']:.0f} vs {e['gemm_8192']['fp16_rocblas_TFLOPs']:.0f} ({e['gemm_8192']['speedup_vs_fp16_rocblas']:.3f}×) |
+| fp16 library GEMM, same shape, same state | on randn operands {e['gemm_4096']['fp16_rocblas_TFLOPs']:.0f} TFLOP/s (ours {e['gemm_4096']['speedup_vs_fp16_rocblas']:.3f}×), on the SAME dequantised operand values {e['gemm_4096']['fp16_rocblas_same_values_TFLOPs']:.0f} (ours {e['gemm_4096']['speedup_vs_fp16_rocblas_same_values']:.3f}×); 8192²: ours {e['gemm_8192']['TFLOPs']:.0f} vs {e['gemm_8192']['fp16_rocblas_TFLOPs']:.0f} ({e['gemm_8192']['speedup_vs_fp16_rocblas']:.3f}×) / {e['gemm_8192']['fp16_rocblas_same_values_TFLOPs']:.0f} ({e['gemm_8192']['speedup_vs_fp16_rocblas_same_values']:.3f}×) |
 | `cpu_baseline` (port of the reference's fake path, {d['cpu_baseline']['cores']} host threads, full workload) | {d['cpu_baseline']['value'] * 1000:.1f} GFLOP/s-equivalent ({cpu_s} s per step) |
 | quantiser, static, graph replay, inputs rotated through > 320 MB | 4096²: {e['quantize_x_4096']['us']:.1f} µs = {e['quantize_x_4096']['GBps'] / 1000:.2f} TB/s ({e['quantize_x_4096'].get('us_same_input', float('nan')):.1f} µs with the same input every launch); 8192²: {e['quantize_x_8192']['us']:.1f} µs = {e['quantize_x_8192']['GBps'] / 1000:.2f} TB/s |
 | Qwen2.5-7B shape, bs = 4, reference protocol (prefill 1024 + 128 decode steps over the growing cache, biases on) | HIP graph: prefill {hg['prefill_ms'][0]:.1f} ms ({hg['prefill_tok_per_s']:.0f} tok/s), decode {hg['decode_ms'][0]:.1f} ± {hg['decode_ms'][1]:.1f} ms = **{hg['decode_tok_per_s']:.0f} tok/s**, e2e {hg['e2e_ms'][0]:.1f} ms, peak {hg['peak_memory_gb']:.1f} GB; eager launches: decode {ea['decode_ms'][0]:.1f} ms = {ea['decode_tok_per_s']:.0f} tok/s |
