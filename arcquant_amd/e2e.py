@@ -70,11 +70,12 @@ class QLinear:
         """Second copy of the weight in MFMA-operand-order tiles for the decode path (agemm.repack_w)."""
         self.RW, self.RSF = agemm.repack_w(self.W, self.SFW)
 
-    def matmul(self, A, SFA, scale, **kw):
-        """GEMM against this weight (+ its bias, in the epilogue): the repacked kernel for decode-sized token counts where available."""
+    def matmul(self, A, SFA, scale, ops=agemm, **kw):
+        """GEMM against this weight (+ its bias, in the epilogue): the repacked kernel for decode-sized token counts where available.
+        ``ops``: the module whose ``matmul_repacked`` is called (the ctypes mirror or the extension module)."""
         kw.setdefault("bias", self.bias)
         if self.RW is not None and agemm.repacked_supported(A.shape[0], self.out_f, self.in_f + self.KE):
-            return agemm.matmul_repacked(A, self.RW, SFA, self.RSF, scale, self.out_f, **kw)
+            return ops.matmul_repacked(A, self.RW, SFA, self.RSF, scale, self.out_f, **kw)
         return agemm.matmul(A, self.W, SFA, self.SFW, scale, **kw)
 
     def bytes(self):
@@ -103,6 +104,15 @@ class DecoderModel:
         # kernel (include/arcq_harness.h; it also appends k / v), "sdpa" / "bmm" = torch (45-48 us per layer at 1040 tokens)
         self.decode_attention = os.environ.get("ARCQ_E2E_DECODE_ATTENTION", "stream" if fused else "sdpa")
         self._attn_ws = None
+        # the decode step's hot calls go through the extension module when it is built (same C-ABI entry points, ~half the host time per
+        # call: an eager step is host-paced through ctypes); ARCQ_E2E_EXT=0 keeps the ctypes mirror
+        self.fast = agemm
+        if fused and os.environ.get("ARCQ_E2E_EXT", "1") == "1":
+            try:
+                from . import _build_ext
+                self.fast = _build_ext.import_agemm_extension()
+            except ImportError:
+                pass
         g = torch.Generator(device=device).manual_seed(0)
         h, it, ke = cfg.hidden_size, cfg.intermediate_size, cfg.select_num
         ab, mb = cfg.attention_bias, cfg.mlp_bias
@@ -123,6 +133,7 @@ class DecoderModel:
         self.idx_h = torch.arange(h, dtype=torch.int16, device=device)
         self.idx_i = torch.arange(it, dtype=torch.int16, device=device)
         self.inv_idx_i = torch.argsort(self.idx_i.long()).to(torch.int16)     # act_scatter_index of the gate|up epilogue
+        agemm._check_scatter_index(self.inv_idx_i, it)                      # (the extension binding does not re-check the permutation)
         self.act_scatter = os.environ.get("ARCQ_E2E_ACT_SCATTER", "1") == "1"
         self.norm = torch.ones(h, dtype=torch.bfloat16, device=device)
         self.lm_head = (torch.randn(cfg.vocab_size, h, generator=g, device=device) * 0.02).to(torch.bfloat16)
@@ -154,7 +165,7 @@ class DecoderModel:
                 Q = L["qkv"]
                 if "qkv" in self.fuse and Q.RW is not None and agemm.fused_supported(agemm.SRC_RMSNORM, T, Q.out_f, h, ke):
                     # decode: ONE launch (the quantiser is the GEMM's prologue; bias in its epilogue)
-                    qkv = agemm.rmsnorm_matmul_repacked(hcur, L["ln1"], cfg.eps, self.idx_h, ke, Q.RW, Q.RSF, Q.scale, Q.out_f, bias=Q.bias)
+                    qkv = self.fast.rmsnorm_matmul_repacked(hcur, L["ln1"], cfg.eps, self.idx_h, ke, Q.RW, Q.RSF, Q.scale, Q.out_f, bias=Q.bias)
                 else:
                     A, SFA = agemm.rmsnorm_quantize_x(hcur, L["ln1"], cfg.eps, self.idx_h, ke)
                     qkv = Q.matmul(A, SFA, Q.scale)
@@ -170,7 +181,7 @@ class DecoderModel:
             if self.fused:
                 O_ = L["o"]
                 if "o" in self.fuse and O_.RW is not None and agemm.fused_supported(agemm.SRC_DYNAMIC, T, O_.out_f, h, ke):
-                    hcur, _ = agemm.dynamic_matmul_repacked(att, self.idx_h, ke, O_.RW, O_.RSF, O_.scale_f, O_.out_f, bias=O_.bias, residual=hcur)
+                    hcur, _ = self.fast.dynamic_matmul_repacked(att, self.idx_h, ke, O_.RW, O_.RSF, O_.scale_f, O_.out_f, bias=O_.bias, residual=hcur)
                 else:
                     qa, sfa, sa = agemm.reorder_quantize_x_dynamic(att, self.idx_h, ke)
                     hcur = O_.matmul(qa, sfa, sa, scale_host=O_.scale_f, residual=hcur)
@@ -186,11 +197,11 @@ class DecoderModel:
                     # "scatter": its epilogue stores the activation in the DOWN projection's channel order, the quantiser below then
                     # reads contiguous groups (reorder_index=None) instead of staging + gathering each row
                     scatter = self.inv_idx_i if self.act_scatter and not (("down" in self.fuse or self.fused_down)) else None
-                    act, slots = agemm.rmsnorm_matmul_repacked_silu(hcur, L["ln2"], cfg.eps, self.idx_h, ke, Gt.RW, Gt.RSF, Gt.scale, Gt.out_f, bias=Gt.bias,
-                                                                    act_scatter_index=scatter)
+                    act, slots = self.fast.rmsnorm_matmul_repacked_silu(hcur, L["ln2"], cfg.eps, self.idx_h, ke, Gt.RW, Gt.RSF, Gt.scale, Gt.out_f, bias=Gt.bias,
+                                                                        act_scatter_index=scatter)
                     if scatter is not None:
-                        qa, sfa, sa = agemm.reorder_quantize_x_dynamic(act, None, ke, absmax_slots=slots)
-                        hcur = D_.matmul(qa, sfa, sa, scale_host=D_.scale_f, residual=hcur)
+                        qa, sfa, sa = self.fast.reorder_quantize_x_dynamic(act, None, ke, absmax_slots=slots)
+                        hcur = D_.matmul(qa, sfa, sa, scale_host=D_.scale_f, residual=hcur, ops=self.fast)
                         continue
                 else:
                     A, SFA = agemm.rmsnorm_quantize_x(hcur, L["ln2"], cfg.eps, self.idx_h, ke)
