@@ -47,8 +47,8 @@ for k, v in pg.items():
     if isinstance(v, dict):
         pre += f"| {k} | {v['us']:.1f} | {v['TFLOPs']:.0f} | {v['frac']:.3f} |\n"
 res = f"""**Results of the committed run** (`profiles/r03_bench_full.json`, one MI355X; the same command under `rocprofv3 --kernel-trace --stats`:
-`profiles/r03_bench_kernel_trace_summary.txt`, `r03_bench_kernel_stats.csv`). Box to box the sustained headline ranged 1369–1379 TFLOP/s this
-round (`roofline.frac` 0.548–0.553), the library GEMM beside it 1436–1447:
+`profiles/r03_bench_kernel_trace_summary.txt`, `r03_bench_kernel_stats.csv`). Box to box the sustained headline ranged 1362–1379 TFLOP/s this
+round (`roofline.frac` 0.546–0.553), the library GEMM beside it 1426–1447 on randn operands:
 
 | what | value |
 |---|---|
