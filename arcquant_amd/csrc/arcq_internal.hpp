@@ -100,5 +100,8 @@ int gemm_skinny(const GemmArgs& a, hipStream_t stream);   // M <= 16, few tiles:
 int64_t gemm_decode_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int gemm_decode(const GemmArgs& a, hipStream_t stream);   // M <= 16, many tiles: 32-row tiles, two units per thread and item
 int gemm_tile(const GemmArgs& a, hipStream_t stream);     // general M: LDS-tiled MFMA GEMM
+// gemm_regtile.hip: 16 < M <~ 1024, grids the tiled kernel cannot fill: operand fragments straight into registers, K split over waves
+int gemm_regtile_cfg(int64_t M, int64_t N, int64_t K, int epilogue);   // 0 = not this kernel, else its configuration
+int gemm_regtile(const GemmArgs& a, int cfg, hipStream_t stream);
 
 }  // namespace arcq

@@ -57,11 +57,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
   constexpr int kT = kMfma32 ? 32 : 16;                   // MFMA tile edge
   constexpr int TM = WM / kT, TN = WN / kT;               // MFMA tiles per wave
   using acc_t = typename std::conditional<kMfma32, f32x16, f32x4>::type;
-  static_assert((BN * 2) % kThreads == 0, "whole staging units per thread");
-  // 16-byte staging units per thread; a short A tile (BM*2 < kThreads) leaves the upper threads without a unit
-  constexpr int A_UNITS = (BM * 2 + kThreads - 1) / kThreads, B_UNITS = BN * 2 / kThreads;
-  constexpr bool A_PARTIAL = (BM * 2) % kThreads != 0;
+  // 16-byte staging units per thread; a short tile edge (BM*2 or BN*2 < kThreads) leaves the upper threads without a unit
+  constexpr int A_UNITS = (BM * 2 + kThreads - 1) / kThreads, B_UNITS = (BN * 2 + kThreads - 1) / kThreads;
+  constexpr bool A_PARTIAL = (BM * 2) % kThreads != 0, B_PARTIAL = (BN * 2) % kThreads != 0;
   static_assert(!A_PARTIAL || A_UNITS == 1, "a partial A pass is a single pass");
+  static_assert(!B_PARTIAL || B_UNITS == 1, "a partial B pass is a single pass");
   constexpr int A_TILE = BM * kRowBytes, B_TILE = BN * kRowBytes;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
   int b_slot[B_UNITS][4];
 #pragma unroll
   for (int u = 0; u < B_UNITS; ++u) {
-    const int unit = tid + u * kThreads, r = unit >> 1, h = unit & 1;
+    const int unit = tid + u * kThreads, r = B_PARTIAL ? min(unit >> 1, BN - 1) : unit >> 1, h = unit & 1;
     const int row = n0 + r, rc = row < p.N ? row : p.N - 1;
     b_q[u] = p.B + (size_t)rc * half_k + h * 16;
     b_sf[u] = p.SFB + sf_atom_offset(rc, 0, atoms_k) + h * 2;
@@ -150,7 +150,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
     for (int u = 0; u < A_UNITS; ++u)
       if (!A_PARTIAL || tid < BM * 2) stage_store(la, a_slot[u], sa[u], a_live[u]);
 #pragma unroll
-    for (int u = 0; u < B_UNITS; ++u) stage_store(lb, b_slot[u], sb[u], b_live[u]);
+    for (int u = 0; u < B_UNITS; ++u)
+      if (!B_PARTIAL || tid < BN * 2) stage_store(lb, b_slot[u], sb[u], b_live[u]);
   };
   auto mma_step = [&](const unsigned char* la, const unsigned char* lb) {
     // weights (B of the GEMM) are the MFMA A operand, so a lane ends up with runs of 4 consecutive n
@@ -202,7 +203,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
     for (int u = 0; u < A_UNITS; ++u)
       if (!A_PARTIAL || tid < BM * 2) stage_store(wa, a_slot[u], ta[u], a_live[u]);
 #pragma unroll
-    for (int u = 0; u < B_UNITS; ++u) stage_store(wb, b_slot[u], tb[u], b_live[u]);
+    for (int u = 0; u < B_UNITS; ++u)
+      if (!B_PARTIAL || tid < BN * 2) stage_store(wb, b_slot[u], tb[u], b_live[u]);
     if (!kStagger || !late) __syncthreads();
   };
 
@@ -233,9 +235,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
         } else {
           const int v = u - A_UNITS < B_UNITS ? u - A_UNITS : 0;
 #ifdef ARCQ_EXPERIMENT_B_RAW
-          stage_piece_raw(nb, b_slot[v][j], tb[v], b_live[v], j);
+          if (!B_PARTIAL || tid < BN * 2) stage_piece_raw(nb, b_slot[v][j], tb[v], b_live[v], j);
 #else
-          stage_piece(nb, b_slot[v][j], tb[v], b_live[v], j);
+          if (!B_PARTIAL || tid < BN * 2) stage_piece(nb, b_slot[v][j], tb[v], b_live[v], j);
 #endif
         }
       }
@@ -421,26 +423,56 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
   }
 }
 
+// ---- tile configurations --------------------------------------------------------------------------------------------------
+// id = the value of ARCQ_TILE_CFG that forces it (debug / tuning only; 0 = heuristic).
+//   1 = 128x128 (4 waves), 2 = 256x256 (4 waves), 3 = 256x256 (8 waves), 4 = 128x256 (4 waves), 5 / 6 = 32x32x16 MFMA variants of
+//   3 / 1, 7 = 64x256 (4 waves), 8 = 32x256 (4 waves), 9 = 1 without split-K; 8-wave tiles for the shapes between decode and
+//   prefill: 10 = 128x256, 11 = 256x128, 12 = 128x128, 13 = 64x256, 14 = 64x128; 4-wave: 15 = 64x64, 16 = 64x128, 17 = 128x64
+struct TileCfg { int id, bm, bn, waves; };
+static constexpr TileCfg kTileCfgs[] = {{1, 128, 128, 4}, {2, 256, 256, 4}, {3, 256, 256, 8}, {4, 128, 256, 4}, {5, 256, 256, 8}, {6, 128, 128, 4},
+                                        {7, 64, 256, 4}, {8, 32, 256, 4}, {9, 128, 128, 4}, {10, 128, 256, 8}, {11, 256, 128, 8}, {12, 128, 128, 8},
+                                        {13, 64, 256, 8}, {14, 64, 128, 8}, {15, 64, 64, 4}, {16, 64, 128, 4}, {17, 128, 64, 4}};
+static const TileCfg& tile_cfg(int id) {
+  for (const TileCfg& c : kTileCfgs)
+    if (c.id == id) return c;
+  return kTileCfgs[2];
+}
+
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+static int tile_cfg_override() {                // ARCQ_TILE_CFG (tuning)
+  static const int v = env_int("ARCQ_TILE_CFG", 0);
+  return v;
+}
+static int tile_split_override() {              // ARCQ_TILE_SPLIT = forced split-K factor (tuning; 0 = by shape)
+  static const int v = env_int("ARCQ_TILE_SPLIT", 0);
+  return v;
+}
+static bool tile_stagger() {                    // ARCQ_TILE_STAGGER=0|1 (tuning)
+  static const int v = env_int("ARCQ_TILE_STAGGER", 0);
+  return v != 0;
+}
+static bool tile_pipe() {                       // ARCQ_TILE_PIPE=0|1 (tuning)
+  static const int v = env_int("ARCQ_TILE_PIPE", 1);
+  return v != 0;
+}
+
 // Split-K factor of a tile shape: split while the tiles alone leave CUs idle, keeping >= 8 atoms (512 K elements)
 // per split so that the prologue/epilogue stay amortised; needs N % 4 == 0 (16-byte partial stores).
 static void tile_split(int64_t M, int64_t N, int64_t K, int BM, int BN, int* splits, int* atoms_per_split) {
   const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   const int atoms = (int)(K / 64);
   int s = 1;
-  if ((N % 4) == 0)
-    while (tiles * s < 256 && atoms / (s * 2) >= 8 && s < 32) s *= 2;
+  if ((N % 4) == 0) {
+    if (tile_split_override() > 0) s = min(tile_split_override(), max(atoms / 2, 1));
+    else
+      while (tiles * s < 256 && atoms / (s * 2) >= 8 && s < 32) s *= 2;
+  }
   const int per = (atoms + s - 1) / s;
   *splits = (atoms + per - 1) / per;      // drop empty splits
   *atoms_per_split = per;
-}
-
-static bool tile_stagger() {                    // ARCQ_TILE_STAGGER=0|1 (tuning)
-  static const int v = getenv("ARCQ_TILE_STAGGER") ? atoi(getenv("ARCQ_TILE_STAGGER")) : 0;
-  return v != 0;
-}
-static bool tile_pipe() {                       // ARCQ_TILE_PIPE=0|1 (tuning)
-  static const int v = getenv("ARCQ_TILE_PIPE") ? atoi(getenv("ARCQ_TILE_PIPE")) : 1;
-  return v != 0;
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool kMfma32 = false, int kEpi = kEpiPlain>
@@ -467,7 +499,7 @@ static int launch_tile(const GemmArgs& a, hipStream_t stream, bool allow_split =
     }
   }
   const size_t lds = 2 * (size_t)(BM + BN) * kRowBytes;
-  constexpr bool kCanStagger = WAVES_M * WAVES_N == 8, kCanPipe = true;
+  constexpr bool kCanStagger = WAVES_M * WAVES_N == 8 && BM == 256 && BN == 256, kCanPipe = true;
   auto kern = gemm_tile_kernel<BM, BN, WAVES_M, WAVES_N, kMfma32, kEpi, false, false>;
   if (kCanPipe && tile_pipe()) kern = gemm_tile_kernel<BM, BN, WAVES_M, WAVES_N, kMfma32, kEpi, false, kCanPipe>;
   else if (kCanStagger && tile_stagger()) kern = gemm_tile_kernel<BM, BN, WAVES_M, WAVES_N, kMfma32, kEpi, kCanStagger, false>;
@@ -482,93 +514,72 @@ static int launch_tile(const GemmArgs& a, hipStream_t stream, bool allow_split =
   return ARCQ_OK;
 }
 
-// ARCQ_TILE_CFG (debug / tuning only): 0 = heuristic, 1 = 128x128 (4 waves), 2 = 256x256 (4 waves),
-// 3 = 256x256 (8 waves), 4 = 128x256 (4 waves), 5/6 = 32x32x16 MFMA variants, 7 = 64x256, 8 = 32x256 (split-K)
-static int tile_cfg_override() {
-  static const int v = [] {
-    const char* e = getenv("ARCQ_TILE_CFG");
-    return e ? atoi(e) : 0;
-  }();
-  return v;
-}
-
 // Shape -> tile: 256x256 with 8 waves (one workgroup per CU, two waves per SIMD) once it yields enough tiles to
 // fill the 256 CUs (measured, tools/gemm_sweep.py: 4096^2 1066 vs 762 TFLOP/s, 8192^2 1347 vs 984); otherwise
 // 128x128 (two workgroups per CU), or a 64- / 32-row tile over 256 weight rows for M <= 64 / 32, each with split-K.
-enum TileKind { kTile256, kTile128, kTile64, kTile32 };
-static TileKind tile_kind(int64_t M, int64_t N) {
+static int tile_choice(int64_t M, int64_t N, int64_t K) {
   const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
-  if (t256 >= 192) return kTile256;
-  if (M <= 32) return kTile32;
-  if (M <= 64) return kTile64;
-  return kTile128;
+  if (t256 >= 192) return 3;
+  if (M <= 32) return 8;
+  if (M <= 64) return 7;
+  // 128 x 256 with 8 waves where it measured faster than 128 x 128 (profiles/r03_midm_tile_sweep.jsonl: M = 2048, N = 4096 65.7 against
+  // 75.7 us, M = 512 31.8 / 37.0, M = 1024 46.2 / 50.3; K = 18944, N = 3584: M = 1024 155 / 164, M = 2048 282 / 307): one exact round of the
+  // chip, half a round, few tiles, or a long K -- elsewhere 128 x 128 (two workgroups per CU) fills the ragged rounds better
+  const int64_t t10 = ((M + 127) / 128) * ((N + 255) / 256);
+  if (t10 <= 64 || t10 == 128 || (t10 > 224 && t10 <= 256) || (K >= 8192 && t10 >= 96 && t10 <= 256)) return 10;
+  return 1;
 }
 
-static int effective_tile_kind(int64_t M, int64_t N) {
-  switch (tile_cfg_override()) {            // tuning override: the forced tile
-    case 0: return (int)tile_kind(M, N);
-    case 1: case 6: case 9: return kTile128;
-    case 7: return kTile64;
-    case 8: return kTile32;
-    case 4: return -4;                      // 128 x 256
-    default: return kTile256;
-  }
+// the configuration a launch uses, and whether it may split K (the silu-mul epilogue never does; 2 - 6 and 9 are the unsplit tuning arms)
+static int effective_cfg(int64_t M, int64_t N, int64_t K, bool* may_split) {
+  int id = tile_cfg_override();
+  if (id == 0) id = tile_choice(M, N, K);
+  id = tile_cfg(id).id;
+  *may_split = !(id >= 2 && id <= 6) && id != 9;
+  return id;
 }
 
 // workgroups (= abs-max slots) of the silu-mul epilogue, which never splits K
 int64_t gemm_tile_silu_slots(int64_t M, int64_t N, int64_t K) {
-  (void)K;
-  int bm = 256, bn = 256;
-  switch (effective_tile_kind(M, N)) {
-    case kTile128: bm = 128; bn = 128; break;
-    case kTile64: bm = 64; bn = 256; break;
-    case kTile32: bm = 32; bn = 256; break;
-    case -4: bm = 128; bn = 256; break;
-    default: break;
-  }
-  return ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+  bool sp;
+  const TileCfg& c = tile_cfg(effective_cfg(M, N, K, &sp));
+  return ((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
 }
 
 int64_t gemm_tile_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   int s = 1, per = 0;
-  const int kind = effective_tile_kind(M, N);
-  switch (kind) {
-    case kTile128: tile_split(M, N, K, 128, 128, &s, &per); break;
-    case kTile64: tile_split(M, N, K, 64, 256, &s, &per); break;
-    case kTile32: tile_split(M, N, K, 32, 256, &s, &per); break;
-    default: break;
-  }
+  bool sp;
+  const TileCfg& c = tile_cfg(effective_cfg(M, N, K, &sp));
+  if (sp) tile_split(M, N, K, c.bm, c.bn, &s, &per);
   return s > 1 ? (int64_t)s * M * N * (int64_t)sizeof(float) : 0;
 }
 
+template <int kEpi>
+static int gemm_tile_epi(const GemmArgs& a, hipStream_t stream) {
+  bool sp;
+  switch (effective_cfg(a.M, a.N, a.K, &sp)) {
+    case 1: case 9: return launch_tile<128, 128, 2, 2, false, kEpi>(a, stream, sp);
+    case 2: return launch_tile<256, 256, 2, 2, false, kEpi>(a, stream);
+    case 4: return launch_tile<128, 256, 2, 2, false, kEpi>(a, stream);
+    case 5: return launch_tile<256, 256, 2, 4, true, kEpi>(a, stream);
+    case 6: return launch_tile<128, 128, 2, 2, true, kEpi>(a, stream);
+    case 7: return launch_tile<64, 256, 1, 4, false, kEpi>(a, stream, sp);
+    case 8: return launch_tile<32, 256, 1, 4, false, kEpi>(a, stream, sp);
+    case 10: return launch_tile<128, 256, 2, 4, false, kEpi>(a, stream, sp);
+    case 11: return launch_tile<256, 128, 4, 2, false, kEpi>(a, stream, sp);
+    case 12: return launch_tile<128, 128, 2, 4, false, kEpi>(a, stream, sp);
+    case 13: return launch_tile<64, 256, 1, 8, false, kEpi>(a, stream, sp);
+    case 14: return launch_tile<64, 128, 2, 4, false, kEpi>(a, stream, sp);
+    case 15: return launch_tile<64, 64, 2, 2, false, kEpi>(a, stream, sp);
+    case 16: return launch_tile<64, 128, 2, 2, false, kEpi>(a, stream, sp);
+    case 17: return launch_tile<128, 64, 2, 2, false, kEpi>(a, stream, sp);
+    default: return launch_tile<256, 256, 2, 4, false, kEpi>(a, stream);
+  }
+}
+
 int gemm_tile(const GemmArgs& a, hipStream_t stream) {
-  if (a.epilogue == kEpiSiluMul) {           // the epilogue is a template parameter: the plain kernels do not carry its exp code
-    switch (effective_tile_kind(a.M, a.N)) {
-      case kTile128: return launch_tile<128, 128, 2, 2, false, kEpiSiluMul>(a, stream);
-      case kTile64: return launch_tile<64, 256, 1, 4, false, kEpiSiluMul>(a, stream);
-      case kTile32: return launch_tile<32, 256, 1, 4, false, kEpiSiluMul>(a, stream);
-      case -4: return launch_tile<128, 256, 2, 2, false, kEpiSiluMul>(a, stream);
-      default: return launch_tile<256, 256, 2, 4, false, kEpiSiluMul>(a, stream);
-    }
-  }
-  switch (tile_cfg_override()) {
-    case 1: return launch_tile<128, 128, 2, 2>(a, stream, true);
-    case 2: return launch_tile<256, 256, 2, 2>(a, stream);
-    case 3: return launch_tile<256, 256, 2, 4>(a, stream);
-    case 4: return launch_tile<128, 256, 2, 2>(a, stream);
-    case 5: return launch_tile<256, 256, 2, 4, true>(a, stream);
-    case 6: return launch_tile<128, 128, 2, 2, true>(a, stream);
-    case 7: return launch_tile<64, 256, 1, 4>(a, stream, true);
-    case 8: return launch_tile<32, 256, 1, 4>(a, stream, true);
-    case 9: return launch_tile<128, 128, 2, 2>(a, stream, false);
-    default: break;
-  }
-  switch (tile_kind(a.M, a.N)) {
-    case kTile256: return launch_tile<256, 256, 2, 4>(a, stream);
-    case kTile64: return launch_tile<64, 256, 1, 4>(a, stream, true);
-    case kTile32: return launch_tile<32, 256, 1, 4>(a, stream, true);
-    default: return launch_tile<128, 128, 2, 2>(a, stream, true);
-  }
+  // the epilogue is a template parameter: the plain kernels do not carry the exp code of silu-mul
+  return a.epilogue == kEpiSiluMul ? gemm_tile_epi<kEpiSiluMul>(a, stream) : gemm_tile_epi<kEpiPlain>(a, stream);
 }
 
 }  // namespace arcq
