@@ -45,7 +45,26 @@ struct RegTileParams {
   float alpha_host;
   int out_dtype;
   int tiles_m, tiles_n;
+#ifdef ARCQ_STREAM_STAMPS
+  unsigned long long* stamps;
+#endif
 };
+
+#ifdef ARCQ_STREAM_STAMPS
+// DIAGNOSTIC build only (make diag, tools/regtile_stamps.py): s_memrealtime (100 MHz) of every wave's lane 0 at five points of the kernel
+static unsigned long long* g_regtile_stamps = nullptr;
+extern "C" void arcq_debug_set_regtile_stamps(void* p) { g_regtile_stamps = reinterpret_cast<unsigned long long*>(p); }
+#define ARCQ_RT_STAMP(k)                                                                                          \
+  do {                                                                                                            \
+    if (p.stamps && lane == 0) {                                                                                  \
+      unsigned long long t_;                                                                                      \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                              \
+      p.stamps[((size_t)blockIdx.x * 16 + wave) * 8 + (k)] = t_;                                                  \
+    }                                                                                                             \
+  } while (0)
+#else
+#define ARCQ_RT_STAMP(k) do { } while (0)
+#endif
 
 typedef uint32_t rt_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t rt_u32x2 __attribute__((ext_vector_type(2)));
@@ -66,6 +85,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KSPLIT * 64) void gemm_regtile_ke
   const int tm = bid % p.tiles_m, tn = bid / p.tiles_m;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: K ranges and loops are wave-uniform
+  ARCQ_RT_STAMP(0);
   const int ks = wave % KSPLIT, wn = (wave / KSPLIT) % WAVES_N, wm = wave / (KSPLIT * WAVES_N);
   const int r = lane & 15, c = lane >> 4;
   const int m0 = tm * BM + wm * 16 * TM, n0 = tn * BN + wn * 16 * TN;
@@ -98,29 +118,29 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KSPLIT * 64) void gemm_regtile_ke
     for (int t = 0; t < TN; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // one quad-step of one operand fragment = two 16-byte halves (slices 0-3 / 4-7) and the atom's four scale bytes.  A step requests the
-  // next step's first halves at its start and the second halves + scales at its middle, when its own first halves are dead: every
+  // next step's first halves + scales at its start and the second halves at its middle, when its own first halves are dead: every
   // load has a full step of lead and at most 3.5 halves per fragment are live (two full stages do not fit 256 registers beside the
   // 64 accumulators: 412 bytes of scratch, measured in the ISA)
   constexpr bool kSliceFence = TM * TN >= 16;     // keep hipcc from dequantising a slice ahead (registers)
   struct Half { rt_u32x4 a[TM], b[TN]; };
   struct Scales { uint32_t a[TM], b[TN]; };
-  auto load_lo = [&](Half& h, int q) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i) h.a[i] = *reinterpret_cast<const rt_u32x4*>((p.A + (size_t)q * 128) + a_off[i]);   // scalar base + 32-bit lane offset
-#pragma unroll
-    for (int t = 0; t < TN; ++t) h.b[t] = *reinterpret_cast<const rt_u32x4*>((p.B + (size_t)q * 128) + b_off[t]);
-  };
-  auto load_hi = [&](Half& h, Scales& sc, int q) __attribute__((always_inline)) {
+  auto load_lo = [&](Half& h, Scales& sc, int q) __attribute__((always_inline)) {     // + the step's scale bytes: needed from its first slice
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      h.a[i] = *reinterpret_cast<const rt_u32x4*>((p.A + (size_t)q * 128 + 16) + a_off[i]);
+      h.a[i] = *reinterpret_cast<const rt_u32x4*>((p.A + (size_t)q * 128) + a_off[i]);   // scalar base + 32-bit lane offset
       sc.a[i] = *reinterpret_cast<const uint32_t*>((p.SFA + (size_t)q * 2048) + a_sfo[i]);
     }
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
-      h.b[t] = *reinterpret_cast<const rt_u32x4*>((p.B + (size_t)q * 128 + 16) + b_off[t]);
+      h.b[t] = *reinterpret_cast<const rt_u32x4*>((p.B + (size_t)q * 128) + b_off[t]);
       sc.b[t] = *reinterpret_cast<const uint32_t*>((p.SFB + (size_t)q * 2048) + b_sfo[t]);
     }
+  };
+  auto load_hi = [&](Half& h, int q) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) h.a[i] = *reinterpret_cast<const rt_u32x4*>((p.A + (size_t)q * 128 + 16) + a_off[i]);
+#pragma unroll
+    for (int t = 0; t < TN; ++t) h.b[t] = *reinterpret_cast<const rt_u32x4*>((p.B + (size_t)q * 128 + 16) + b_off[t]);
   };
   // four MFMA K slices: slice j = dword j of the half, scale byte 2 * half + j / 2.  Weights are the MFMA A operand (rows = weight
   // rows), activations the B operand (columns = tokens): a lane ends up with four consecutive output columns n of one token
@@ -139,31 +159,70 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KSPLIT * 64) void gemm_regtile_ke
       if (kSliceFence) __builtin_amdgcn_sched_barrier(0);
     }
   };
-  // three sets of halves rotate: step s reads lo(s) = S[2s % 3] and hi(s) = S[(2s + 1) % 3], requests lo(s + 1) into the third set at its
-  // start and hi(s + 1) into lo(s)'s set at its middle -- a period of three steps, unrolled, so that no set is ever moved
-  Half s0, s1, s2;
-  Scales c0, c1, c2;
-  auto step = [&](const Half& lo, const Half& hi, const Scales& sc, Half& lon, Half& hin, Scales& scn, int q) __attribute__((always_inline)) {
-    const bool more = q + 1 < qe;                                  // wave-uniform (scalar)
-    if (more) load_lo(lon, q + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_half(lo, sc, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) load_hi(hin, scn, q + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_half(hi, sc, 1);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  if (qb < qe) {
-    load_lo(s0, qb);
-    load_hi(s1, c0, qb);
-  }
+  if constexpr (TM * TN >= 16) {
+    // three sets of halves rotate: step s reads lo(s) = S[2s % 3] and hi(s) = S[(2s + 1) % 3], requests lo(s + 1) into the third set at its
+    // start and hi(s + 1) into lo(s)'s set at its middle -- a period of three steps, unrolled, so that no set is ever moved
+    Half s0, s1, s2;
+    Scales c0, c1, c2;
+    auto step = [&](const Half& lo, const Half& hi, const Scales& sc, Half& lon, Half& hin, Scales& scn, int q) __attribute__((always_inline)) {
+      const bool more = q + 1 < qe;                                  // wave-uniform (scalar)
+      if (more) load_lo(lon, scn, q + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(lo, sc, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) load_hi(hin, q + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(hi, sc, 1);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    if (qb < qe) {
+      load_lo(s0, c0, qb);
+      load_hi(s1, qb);
+    }
+#ifdef ARCQ_STREAM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (diagnostic build: the first step's operands have arrived)
+    ARCQ_RT_STAMP(1);
+#endif
 #pragma unroll 1
-  for (int q = qb; q < qe; q += 3) {
-    step(s0, s1, c0, s2, s0, c1, q);
-    if (q + 1 < qe) step(s2, s0, c1, s1, s2, c2, q + 1);
-    if (q + 2 < qe) step(s1, s2, c2, s0, s1, c0, q + 2);
+    for (int q = qb; q < qe; q += 3) {
+      step(s0, s1, c0, s2, s0, c1, q);
+      if (q + 1 < qe) step(s2, s0, c1, s1, s2, c2, q + 1);
+      if (q + 2 < qe) step(s1, s2, c2, s0, s1, c0, q + 2);
+    }
+  } else {
+    // smaller wave tiles: a ring of whole steps, kStages - 1 of them in flight while one is multiplied (a step of a 2 x 2 tile is 32 MFMAs:
+    // one step of lead does not cover a loaded memory latency; the registers the 64 accumulators would take hold the ring instead)
+    constexpr int kStages = TM * TN <= 4 ? 4 : 3;
+    Half rlo[kStages], rhi[kStages];
+    Scales rsc[kStages];
+#pragma unroll
+    for (int d = 0; d < kStages - 1; ++d)
+      if (qb + d < qe) {
+        load_lo(rlo[d], rsc[d], qb + d);
+        load_hi(rhi[d], qb + d);
+      }
+#ifdef ARCQ_STREAM_STAMPS
+    ARCQ_RT_STAMP(1);
+#endif
+#pragma unroll 1
+    for (int q = qb; q < qe; q += kStages) {
+#pragma unroll
+      for (int u = 0; u < kStages; ++u) {
+        if (q + u < qe) {
+          constexpr int kLead = kStages - 1;
+          if (q + u + kLead < qe) {
+            load_lo(rlo[(u + kLead) % kStages], rsc[(u + kLead) % kStages], q + u + kLead);
+            load_hi(rhi[(u + kLead) % kStages], q + u + kLead);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          mma_half(rlo[u], rsc[u], 0);
+          mma_half(rhi[u], rsc[u], 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
   }
+  ARCQ_RT_STAMP(2);
   // ---- tail atoms (K % 256 != 0): lane (r, c) takes group c of the atom (8 bytes), its scale is byte c of the atom's dword
 #pragma unroll 1
   for (int e = 0; e < R; ++e) {
@@ -194,6 +253,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KSPLIT * 64) void gemm_regtile_ke
         for (int t = 0; t < TN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[j][t].v, xa[j][i].v, acc[i][t], 0, 0, 0);
   }
 
+  ARCQ_RT_STAMP(3);
   // ---- the K splits meet in LDS: [wave][tile][lane] float4; split ks then finishes tiles ks, ks + KSPLIT, ... of its (wm, wn) block
   const float alpha = p.alpha_host * (p.alpha_dev ? *p.alpha_dev : 1.0f);
   auto finish_tile = [&](int i, int t, const f32x4& s) __attribute__((always_inline)) {
@@ -230,6 +290,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KSPLIT * 64) void gemm_regtile_ke
       }
     }
   }
+  ARCQ_RT_STAMP(4);
   (void)kWaves;
 }
 
@@ -255,6 +316,9 @@ static int launch_regtile(const GemmArgs& a, hipStream_t stream) {
   constexpr int BM = 16 * TM * WAVES_M, BN = 16 * TN * WAVES_N, kWaves = WAVES_M * WAVES_N * KSPLIT;
   p.tiles_m = (a.M + BM - 1) / BM;
   p.tiles_n = (a.N + BN - 1) / BN;
+#ifdef ARCQ_STREAM_STAMPS
+  p.stamps = g_regtile_stamps;
+#endif
   const int lds = KSPLIT > 1 ? kWaves * TM * TN * 64 * 16 : 0;
   auto kern = gemm_regtile_kernel<TM, TN, WAVES_M, WAVES_N, KSPLIT>;
   static LdsOptIn lds_opt;
