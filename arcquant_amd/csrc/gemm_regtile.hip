@@ -125,6 +125,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KSPLIT * 64) void gemm_regtile_ke
   struct Half { rt_u32x4 a[TM], b[TN]; };
   struct Scales { uint32_t a[TM], b[TN]; };
   auto load_lo = [&](Half& h, Scales& sc, int q) __attribute__((always_inline)) {     // + the step's scale bytes: needed from its first slice
+#ifdef ARCQ_EXPERIMENT_RT_NOLOAD
+    // TIMING EXPERIMENT ONLY (results are WRONG): no operand is loaded, the multiply runs on register contents
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { h.a[i] = rt_u32x4{(uint32_t)q, a_off[i], 0x12345678u, 0x9abcdef0u}; sc.a[i] = 0x38383838u; }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) { h.b[t] = rt_u32x4{(uint32_t)q, b_off[t], 0x12345678u, 0x9abcdef0u}; sc.b[t] = 0x38383838u; }
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       h.a[i] = *reinterpret_cast<const rt_u32x4*>((p.A + (size_t)q * 128) + a_off[i]);   // scalar base + 32-bit lane offset
@@ -137,6 +145,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KSPLIT * 64) void gemm_regtile_ke
     }
   };
   auto load_hi = [&](Half& h, int q) __attribute__((always_inline)) {
+#ifdef ARCQ_EXPERIMENT_RT_NOLOAD
+#pragma unroll
+    for (int i = 0; i < TM; ++i) h.a[i] = rt_u32x4{(uint32_t)q, a_off[i], 0x12345678u, 0x9abcdef0u};
+#pragma unroll
+    for (int t = 0; t < TN; ++t) h.b[t] = rt_u32x4{(uint32_t)q, b_off[t], 0x12345678u, 0x9abcdef0u};
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < TM; ++i) h.a[i] = *reinterpret_cast<const rt_u32x4*>((p.A + (size_t)q * 128 + 16) + a_off[i]);
 #pragma unroll
@@ -145,6 +160,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KSPLIT * 64) void gemm_regtile_ke
   // four MFMA K slices: slice j = dword j of the half, scale byte 2 * half + j / 2.  Weights are the MFMA A operand (rows = weight
   // rows), activations the B operand (columns = tokens): a lane ends up with four consecutive output columns n of one token
   auto mma_half = [&](const Half& h, const Scales& sc, int half) __attribute__((always_inline)) {
+#ifdef ARCQ_EXPERIMENT_RT_NOCOMPUTE
+    // TIMING EXPERIMENT ONLY (results are WRONG): the operands are awaited and folded into one accumulator, nothing is multiplied
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[0][0][0] += __builtin_bit_cast(float, h.a[i][0] ^ h.a[i][1] ^ h.a[i][2] ^ h.a[i][3] ^ (sc.a[i] & 0x7f7f7f7f));
+#pragma unroll
+    for (int t = 0; t < TN; ++t) acc[0][0][1] += __builtin_bit_cast(float, h.b[t][0] ^ h.b[t][1] ^ h.b[t][2] ^ h.b[t][3] ^ (sc.b[t] & 0x7f7f7f7f));
+    (void)half;
+    return;
+#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       Frag8 xa[TM], xb[TN];
