@@ -124,7 +124,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KSPLIT * 64) void gemm_regtile_ke
   constexpr bool kSliceFence = TM * TN >= 16;     // keep hipcc from dequantising a slice ahead (registers)
   struct Half { rt_u32x4 a[TM], b[TN]; };
   struct Scales { uint32_t a[TM], b[TN]; };
-  auto load_lo = [&](Half& h, Scales& sc, int q) __attribute__((always_inline)) {     // + the step's scale bytes: needed from its first slice
+  // buffer loads: descriptor (scalar) + the fragment's 32-bit lane offset + the step's scalar offset -- no 64-bit address is ever formed in
+  // vector registers.  (With global loads hipcc built the addresses in registers that were still the targets of loads in flight and had to
+  // wait for ALL of them before it could request the next step: M = 256 19.6 us, loads and multiplies one after the other.)
+  const auto rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.A), 0, p.M * half_k, 0x00020000);
+  const auto rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.B), 0, p.N * half_k, 0x00020000);
+  const auto rs_sa = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.SFA), 0, ((p.M + 127) >> 7) * atoms_k * 512, 0x00020000);
+  const auto rs_sb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.SFB), 0, ((p.N + 127) >> 7) * atoms_k * 512, 0x00020000);
+  auto load_lo = [&](Half& h, Scales& sc, int q, uint32_t drop = 0u) __attribute__((always_inline)) {     // + the step's scale bytes: needed from its first slice
 #ifdef ARCQ_EXPERIMENT_RT_NOLOAD
     // TIMING EXPERIMENT ONLY (results are WRONG): no operand is loaded, the multiply runs on register contents
 #pragma unroll
@@ -135,16 +142,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KSPLIT * 64) void gemm_regtile_ke
 #endif
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      h.a[i] = *reinterpret_cast<const rt_u32x4*>((p.A + (size_t)q * 128) + a_off[i]);   // scalar base + 32-bit lane offset
-      sc.a[i] = *reinterpret_cast<const uint32_t*>((p.SFA + (size_t)q * 2048) + a_sfo[i]);
+      h.a[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_off[i] | drop, q * 128, 0);
+      sc.a[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_sa, a_sfo[i] | drop, q * 2048, 0);
     }
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
-      h.b[t] = *reinterpret_cast<const rt_u32x4*>((p.B + (size_t)q * 128) + b_off[t]);
-      sc.b[t] = *reinterpret_cast<const uint32_t*>((p.SFB + (size_t)q * 2048) + b_sfo[t]);
+      h.b[t] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, b_off[t] | drop, q * 128, 0);
+      sc.b[t] = __builtin_amdgcn_raw_buffer_load_b32(rs_sb, b_sfo[t] | drop, q * 2048, 0);
     }
   };
-  auto load_hi = [&](Half& h, int q) __attribute__((always_inline)) {
+  auto load_hi = [&](Half& h, int q, uint32_t drop = 0u) __attribute__((always_inline)) {
 #ifdef ARCQ_EXPERIMENT_RT_NOLOAD
 #pragma unroll
     for (int i = 0; i < TM; ++i) h.a[i] = rt_u32x4{(uint32_t)q, a_off[i], 0x12345678u, 0x9abcdef0u};
@@ -153,9 +160,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KSPLIT * 64) void gemm_regtile_ke
     return;
 #endif
 #pragma unroll
-    for (int i = 0; i < TM; ++i) h.a[i] = *reinterpret_cast<const rt_u32x4*>((p.A + (size_t)q * 128 + 16) + a_off[i]);
+    for (int i = 0; i < TM; ++i) h.a[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (a_off[i] | drop) + 16, q * 128, 0);
 #pragma unroll
-    for (int t = 0; t < TN; ++t) h.b[t] = *reinterpret_cast<const rt_u32x4*>((p.B + (size_t)q * 128 + 16) + b_off[t]);
+    for (int t = 0; t < TN; ++t) h.b[t] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (b_off[t] | drop) + 16, q * 128, 0);
   };
   // four MFMA K slices: slice j = dword j of the half, scale byte 2 * half + j / 2.  Weights are the MFMA A operand (rows = weight
   // rows), activations the B operand (columns = tokens): a lane ends up with four consecutive output columns n of one token
@@ -185,42 +192,50 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KSPLIT * 64) void gemm_regtile_ke
   };
   if constexpr (TM * TN >= 16) {
     // three sets of halves rotate: step s reads lo(s) = S[2s % 3] and hi(s) = S[(2s + 1) % 3], requests lo(s + 1) into the third set at its
-    // start and hi(s + 1) into lo(s)'s set at its middle -- a period of three steps, unrolled, so that no set is ever moved
+    // start and hi(s + 1) into lo(s)'s set at its middle -- a period of three steps, unrolled, so that no set is ever moved.  Every step
+    // ISSUES its requests, also the wave's last one: there with bit 31 set in every lane offset, which the descriptor's range check drops
+    // without touching memory.  Exits leave the loop and never rejoin it, so on the one straight path through it the number of loads in
+    // flight at every wait is a constant and hipcc waits for exactly the operands of the slice it is about to multiply (with `if (more) load`
+    // inside the step it drained the queue at every join; a peeled copy of the last step per phase instead cost 1.2 KB of scratch)
+    constexpr uint32_t kDrop = 0x80000000u;
     Half s0, s1, s2;
     Scales c0, c1, c2;
     auto step = [&](const Half& lo, const Half& hi, const Scales& sc, Half& lon, Half& hin, Scales& scn, int q) __attribute__((always_inline)) {
-      const bool more = q + 1 < qe;                                  // wave-uniform (scalar)
-      if (more) load_lo(lon, scn, q + 1);
+      const uint32_t drop = q + 1 < qe ? 0u : kDrop;                 // wave-uniform (scalar)
+      load_lo(lon, scn, q + 1, drop);
       __builtin_amdgcn_sched_barrier(0);
       mma_half(lo, sc, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (more) load_hi(hin, q + 1);
+      load_hi(hin, q + 1, drop);
       __builtin_amdgcn_sched_barrier(0);
       mma_half(hi, sc, 1);
       __builtin_amdgcn_sched_barrier(0);
     };
     if (qb < qe) {
-      load_lo(s0, c0, qb);
-      load_hi(s1, qb);
-    }
+      load_lo(s0, c0, qb, 0u);
+      load_hi(s1, qb, 0u);
 #ifdef ARCQ_STREAM_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (diagnostic build: the first step's operands have arrived)
-    ARCQ_RT_STAMP(1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (diagnostic build: the first step's operands have arrived)
+      ARCQ_RT_STAMP(1);
 #endif
 #pragma unroll 1
-    for (int q = qb; q < qe; q += 3) {
-      step(s0, s1, c0, s2, s0, c1, q);
-      if (q + 1 < qe) step(s2, s0, c1, s1, s2, c2, q + 1);
-      if (q + 2 < qe) step(s1, s2, c2, s0, s1, c0, q + 2);
+      for (int q = qb;; q += 3) {
+        step(s0, s1, c0, s2, s0, c1, q);
+        if (q + 1 >= qe) break;
+        step(s2, s0, c1, s1, s2, c2, q + 1);
+        if (q + 2 >= qe) break;
+        step(s1, s2, c2, s0, s1, c0, q + 2);
+        if (q + 3 >= qe) break;
+      }
     }
   } else {
     // smaller wave tiles: a ring of whole steps, kStages - 1 of them in flight while one is multiplied (a step of a 2 x 2 tile is 32 MFMAs:
     // one step of lead does not cover a loaded memory latency; the registers the 64 accumulators would take hold the ring instead)
-    constexpr int kStages = TM * TN <= 4 ? 4 : 3;
+    constexpr int kStages = TM * TN <= 4 ? 4 : 3, kLead = kStages - 1;
     Half rlo[kStages], rhi[kStages];
     Scales rsc[kStages];
 #pragma unroll
-    for (int d = 0; d < kStages - 1; ++d)
+    for (int d = 0; d < kLead; ++d)
       if (qb + d < qe) {
         load_lo(rlo[d], rsc[d], qb + d);
         load_hi(rhi[d], qb + d);
@@ -233,7 +248,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KSPLIT * 64) void gemm_regtile_ke
 #pragma unroll
       for (int u = 0; u < kStages; ++u) {
         if (q + u < qe) {
-          constexpr int kLead = kStages - 1;
           if (q + u + kLead < qe) {
             load_lo(rlo[(u + kLead) % kStages], rsc[(u + kLead) % kStages], q + u + kLead);
             load_hi(rhi[(u + kLead) % kStages], q + u + kLead);
@@ -354,14 +368,15 @@ static int launch_regtile(const GemmArgs& a, hipStream_t stream) {
   return ARCQ_OK;
 }
 
-// 0 = the tiled kernel serves this shape, else the configuration.  Measured (tools/midm_tile_sweep.py, profiles/r03_midm_tile_sweep.jsonl,
-// sustained launches, us, this kernel / the tiled kernel's best configuration): N = K = 4096: M = 32 9.4 / 16.3, 64 9.5 / 20.3, 128 10.4 /
-// 20.9, 256 19.7 / 26.1, 512 29.7 / 32.0, 1024 49.7 / 46.1; N = 10752, K = 3584: M = 64 18.1 / 24.3, 128 27.2 / 28.4, 256 51.6 / 43.7;
-// N = 3584, K = 18944: M = 64 25.4 / 33.8, 128 35.8 / 35.6, 256 58.6 / 53.4 -- i.e. up to ~9 GFLOP-equivalents of M N K and M <= 512, as
-// long as the grid of its smallest useful tile still covers a good part of the chip.
+// 0 = the tiled kernel serves this shape, else the configuration: the SMALLEST tile whose grid is one round of the chip (<= 256 workgroups;
+// >= 96, or the tiled kernel's split-K fills the chip better), up to ~1.6 * 10^10 of M N K, where the tiled kernel's one dequantisation per
+// workgroup starts to win.  Measured (tools/midm_tile_sweep.py, profiles/r03_midm_regtile_sweep.jsonl; graph replay, us, this kernel / the tiled
+// kernel): N = K = 4096: M = 32 9.0 / 15.7, 64 9.1 / 20.6, 128 11.3 / 25.8, 256 16.8 / 27.2, 512 27.5 / 32.6, 1024 46.8 / 46.5;
+// N = 10752, K = 3584: M = 32 11.4 / 20.1, 64 15.4 / 25.9, 128 25.9 / 28.7, 256 40.8 / 43.9, 512 75.6 / 65.0; N = 3584, K = 18944: M = 64 25.2 /
+// 34.1, 128 35.8 / 46.2, 256 54.3 / 59.6, 512 94.6 / 92.4, 1024 172 / 156.
 int gemm_regtile_cfg(int64_t M, int64_t N, int64_t K, int epilogue) {
   if (epilogue != kEpiPlain || M <= 16 || (K & 63) != 0) return 0;
-  if ((int64_t)max(M, N) * (K / 2) >= ((int64_t)1 << 31)) return 0;          // 32-bit lane offsets
+  if ((int64_t)max(M, N) * (K / 2) >= ((int64_t)1 << 31) || ((max(M, N) + 127) / 128) * (K / 64) * 512 >= ((int64_t)1 << 31)) return 0;   // 32-bit offsets, buffer descriptors
   const int ov = regtile_override();
   if (ov < 0) return 0;
   if (ov > 0) {
@@ -369,11 +384,15 @@ int gemm_regtile_cfg(int64_t M, int64_t N, int64_t K, int epilogue) {
       if (c.id == ov) return ov;
     return 0;
   }
-  if (M > 512 || (double)M * (double)N * (double)K > 9.0e9) return 0;
-  const int id = M <= 64 ? 7 : M <= 128 ? 6 : M <= 256 ? 1 : 8;
-  for (const RegCfg& c : kRegCfgs)
-    if (c.id == id && ((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn) < 96) return 0;   // too few workgroups: the tiled kernel splits K over them
-  return id;
+  if ((double)M * (double)N * (double)K > 1.6e10) return 0;
+  static const int order[] = {7, 6, 5, 1, 8, 2, 3};           // by tile area, token-narrow before row-narrow
+  for (int id : order)
+    for (const RegCfg& c : kRegCfgs) {
+      if (c.id != id || (c.bm > 32 && c.bm >= 2 * M)) continue;       // a tile twice as tall as the batch multiplies padding
+      const int64_t wgs = ((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
+      if (wgs <= 256) return wgs >= 96 ? id : 0;
+    }
+  return 0;
 }
 
 int gemm_regtile(const GemmArgs& a, int cfg, hipStream_t stream) {

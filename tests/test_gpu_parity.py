@@ -201,13 +201,17 @@ GEMM_CASES = [
     (4, 5120, 64, 0, O.G16),          # K = 64: a single scale atom, on each of the three kernels
     (3, 200, 64, 0, O.G16),
     (40, 256, 64, 0, O.G16),
-    # gemm_regtile.hip (16 < M <= 512 with a grid of >= 96 workgroups): every configuration its heuristic picks, K tails of 1 / 2 / 3 atoms
+    # gemm_regtile.hip (16 < M, one round of <= 256 and >= 96 workgroups of its smallest fitting tile): every configuration its heuristic
+    # picks, K tails of 0 / 1 / 2 / 3 atoms
     (24, 3104, 256, 64, O.G16),       # 32 x 32 tiles (2 x 2 MFMA tiles per wave, ring of 4 steps), one quad-step + 1 tail atom, 24 live token rows
     (64, 1600, 2112, 64, O.G16),      # ... 8 quad-steps over 8 waves + 2 tail atoms
-    (100, 1550, 320, 64, O.G32),      # 64 x 32 tiles, ragged M and N (N % 16 != 0, N % 4 != 0: scalar stores), 2 tail atoms
-    (200, 1540, 384, 64, O.G16),      # 64 x 64 tiles (half-step prefetch), 3 tail atoms, N % 16 = 4
+    (32, 8200, 256, 64, O.G16),       # 32 x 64 tiles (the 32 x 32 grid would exceed one round)
+    (100, 2110, 320, 64, O.G32),      # 64 x 32 tiles, ragged M and N (N % 16 != 0, N % 4 != 0: scalar stores), 2 tail atoms
     (256, 2048, 1024, 0, O.G16),      # ... K % 256 == 0: no tail, 4 quad-steps over 8 waves (some waves idle)
-    (300, 2052, 576, 64, O.G16),      # 128 x 64 tiles (waves 2 x 1 x 4), 2 tail atoms
+    (200, 2500, 384, 64, O.G16),      # 64 x 64 tiles (half-step prefetch, droppable requests), 3 tail atoms, N % 16 = 4
+    (300, 4100, 576, 64, O.G16),      # 128 x 64 tiles (waves 2 x 1 x 4), 2 tail atoms
+    (192, 10000, 256, 64, O.G16),     # 64 x 128 tiles (waves 1 x 2 x 4)
+    (256, 10752, 256, 64, O.G16),     # 128 x 128 tiles (waves 2 x 2 x 2)
 ]
 
 
@@ -608,11 +612,11 @@ def test_silu_mul_gemm_epilogue_equals_the_unfused_steps():
 
 def test_gemm_epilogue_operands_on_every_kernel():
     """bias + residual + device scale through the 16-row decode kernel, the 32-row decode kernel, the register-tiled kernel
-    (gemm_regtile.hip: 128 x 64, 32 x 32, 64 x 32 and 64 x 64 tiles), the split-K tile path and the 128 x 128 tile: the fused epilogue equals the separate torch ops on the plain result, and doubling
+    (gemm_regtile.hip: 64 x 64, 32 x 32, 64 x 32, 64 x 64 and 128 x 64 tiles), the split-K tile path and the 128 x 128 tile: the fused epilogue equals the separate torch ops on the plain result, and doubling
     alpha doubles the fp32 output exactly (linearity in the per-tensor scale; a power of two commutes with every
     rounding)."""
     ag = _agemm()
-    for (M, N, KQ) in [(4, 384, 512), (4, 5120, 512), (40, 512, 1984), (300, 2048, 256), (60, 3200, 512), (128, 1600, 256), (250, 1600, 320), (1100, 256, 256)]:
+    for (M, N, KQ) in [(4, 384, 512), (4, 5120, 512), (40, 512, 1984), (300, 2048, 256), (60, 3200, 512), (128, 2100, 256), (250, 2500, 320), (300, 4100, 256), (1100, 256, 256)]:
         qx, sfx, qw, sfw, alpha = _make_operands(M, N, KQ, 64, O.G16, 3 * M + N)
         A, B = torch.from_numpy(qx).to(DEV), torch.from_numpy(qw).to(DEV)
         SFA, SFB = torch.from_numpy(sfx).to(DEV), torch.from_numpy(sfw).to(DEV)

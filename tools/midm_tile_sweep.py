@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The tile GEMM between decode and prefill (M = 128 ... 2048): every tile configuration x forced split-K factor, each arm in its own
-process (the switches are read once), sustained launches.  usage: python tools/midm_tile_sweep.py   (parent makes no GPU call)
+process (the switches are read once), sustained launches replayed from a HIP graph (SWEEP_GRAPH=0: eager, host-bound below ~9.5 us).  usage: python tools/midm_tile_sweep.py   (parent makes no GPU call)
   SWEEP_ARMS="0:0,1:0,10:0,12:2,r1:0"  (ARCQ_TILE_CFG:ARCQ_TILE_SPLIT; split 0 = the launcher's own choice; rN = ARCQ_REGTILE_CFG=N, gemm_regtile.hip)   SWEEP_MS, SWEEP_NK"""
 import json
 import os
@@ -18,11 +18,47 @@ def child():
     from arcquant_amd import agemm
     from bench import make_problem, time_events_steady
     dev = torch.device("cuda:0")
+    bufs = {}
+
+    def out_buf(m, n):
+        if (m, n) not in bufs:
+            bufs.clear()
+            bufs[(m, n)] = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+        return bufs[(m, n)]
+
+    def graph_us(fn, per_graph=20):
+        """us per launch, `per_graph` launches replayed from one HIP graph (an eager launch through the ctypes mirror costs ~9.5 us of
+        host time: below that an eager loop measures the host)"""
+        fn()
+        torch.cuda.synchronize()
+        g, st = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            fn()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=st):
+                for _ in range(per_graph):
+                    fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(30):
+            g.replay()
+        torch.cuda.synchronize()
+        e0.record()
+        reps = 40
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / (reps * per_graph)
+
     for (n, kq) in NK:
         for m in MS:
             q = make_problem(m, n, kq, 64, dev)
             try:
-                t = time_events_steady(lambda: agemm.matmul(q["qx"], q["qw"], q["sfx"], q["sfw"], q["alpha"]), 50, 20.0)
+                if os.environ.get("SWEEP_GRAPH", "1") == "1":
+                    t = graph_us(lambda: agemm.matmul(q["qx"], q["qw"], q["sfx"], q["sfw"], q["alpha"], out=out_buf(m, n)))
+                else:
+                    t = time_events_steady(lambda: agemm.matmul(q["qx"], q["qw"], q["sfx"], q["sfw"], q["alpha"]), 50, 20.0)
                 print(json.dumps({"shape": [m, n, kq], "us": round(t, 2)}), flush=True)
             except Exception as e:
                 print(json.dumps({"shape": [m, n, kq], "error": repr(e)[:100]}), flush=True)
