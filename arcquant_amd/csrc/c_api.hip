@@ -113,8 +113,8 @@ static bool use_decode_v2(int64_t N) {
 
 int64_t arcq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  if (M <= kSkinnyMaxM) return use_decode_v2(N) ? gemm_decode_workspace_bytes(M, N, K) : gemm_skinny_workspace_bytes(M, N, K);
   if (gemm_regtile_cfg(M, N, K, kEpiPlain)) return 0;
+  if (M <= kSkinnyMaxM) return use_decode_v2(N) ? gemm_decode_workspace_bytes(M, N, K) : gemm_skinny_workspace_bytes(M, N, K);
   return gemm_tile_workspace_bytes(M, N, K);
 }
 
@@ -138,8 +138,8 @@ int arcq_gemm_nvfp4(const uint8_t* A, const uint8_t* B, const uint8_t* SFA, cons
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.alpha_host = alpha_host; a.alpha_dev = alpha_dev; a.bias = (const uint16_t*)bias; a.residual = (const uint16_t*)residual; a.out_dtype = out_dtype;
   a.workspace = workspace; a.workspace_bytes = workspace_bytes;
-  if (M <= kSkinnyMaxM) return use_decode_v2(N) ? gemm_decode(a, (hipStream_t)stream) : gemm_skinny(a, (hipStream_t)stream);
   if (const int cfg = gemm_regtile_cfg(M, N, K, kEpiPlain)) return gemm_regtile(a, cfg, (hipStream_t)stream);
+  if (M <= kSkinnyMaxM) return use_decode_v2(N) ? gemm_decode(a, (hipStream_t)stream) : gemm_skinny(a, (hipStream_t)stream);
   return gemm_tile(a, (hipStream_t)stream);
 }
 

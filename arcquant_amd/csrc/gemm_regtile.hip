@@ -1,5 +1,5 @@
-// ARC-NVFP4 GEMM for the shapes between decode and prefill (16 < M <~ 1024 on the reference layout): a register-tiled fp16-MFMA
-// kernel WITHOUT an LDS operand stage, K split over the waves of a workgroup.
+// ARC-NVFP4 GEMM for decode on the reference layout (M <= 16) and the shapes between decode and prefill (16 < M <~ 1024): a register-tiled
+// fp16-MFMA kernel WITHOUT an LDS operand stage, K split over the waves of a workgroup.
 //
 // Why not the LDS-tiled kernel (gemm_tile.hip) here: with few tokens the grid of 128 x 128 / 256 x 256 tiles does not fill 256 CUs, so
 // that kernel splits K over workgroups (fp32 partial planes + a finish launch: 16.8 MB written and re-read at M = 256, N = 4096) and
@@ -336,9 +336,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KSPLIT * 64) void gemm_regtile_ke
 // configurations (ARCQ_REGTILE_CFG forces one, tuning only): token tiles x row tiles per wave, waves along M / N / K
 //   1 = 4x4 1x1x8 (64 x 64 per workgroup)   2 = 4x4 1x2x4 (64 x 128)   3 = 4x4 2x2x2 (128 x 128)   4 = 4x4 2x4x1 (128 x 256)
 //   5 = 2x4 1x1x8 (32 x 64)                 6 = 4x2 1x1x8 (64 x 32)     7 = 2x2 1x1x8 (32 x 32)     8 = 4x4 2x1x4 (128 x 64)
+//   9 = 1x1 1x1x8 (16 x 16)                 10 = 1x2 1x1x8 (16 x 32)    11 = 1x4 1x1x8 (16 x 64)    (decode batches on the reference layout)
 struct RegCfg { int id, bm, bn, ksplit, tm, tn; };
 static constexpr RegCfg kRegCfgs[] = {{1, 64, 64, 8, 4, 4}, {2, 64, 128, 4, 4, 4}, {3, 128, 128, 2, 4, 4}, {4, 128, 256, 1, 4, 4},
-                                      {5, 32, 64, 8, 2, 4}, {6, 64, 32, 8, 4, 2},  {7, 32, 32, 8, 2, 2},   {8, 128, 64, 4, 4, 4}};
+                                      {5, 32, 64, 8, 2, 4}, {6, 64, 32, 8, 4, 2},  {7, 32, 32, 8, 2, 2},   {8, 128, 64, 4, 4, 4},
+                                      {9, 16, 16, 8, 1, 1}, {10, 16, 32, 8, 1, 2}, {11, 16, 64, 8, 1, 4}};
 
 static int regtile_override() {              // ARCQ_REGTILE_CFG: 0 = by shape, -1 = never (the tiled kernel), n = forced configuration
   static const int v = getenv("ARCQ_REGTILE_CFG") ? atoi(getenv("ARCQ_REGTILE_CFG")) : 0;
@@ -375,13 +377,21 @@ static int launch_regtile(const GemmArgs& a, hipStream_t stream) {
 // N = 10752, K = 3584: M = 32 11.4 / 20.1, 64 15.4 / 25.9, 128 25.9 / 28.7, 256 40.8 / 43.9, 512 75.6 / 65.0; N = 3584, K = 18944: M = 64 25.2 /
 // 34.1, 128 35.8 / 46.2, 256 54.3 / 59.6, 512 94.6 / 92.4, 1024 172 / 156.
 int gemm_regtile_cfg(int64_t M, int64_t N, int64_t K, int epilogue) {
-  if (epilogue != kEpiPlain || M <= 16 || (K & 63) != 0) return 0;
+  if (epilogue != kEpiPlain || (K & 63) != 0) return 0;
   if ((int64_t)max(M, N) * (K / 2) >= ((int64_t)1 << 31) || ((max(M, N) + 127) / 128) * (K / 64) * 512 >= ((int64_t)1 << 31)) return 0;   // 32-bit offsets, buffer descriptors
   const int ov = regtile_override();
   if (ov < 0) return 0;
   if (ov > 0) {
     for (const RegCfg& c : kRegCfgs)
       if (c.id == ov) return ov;
+    return 0;
+  }
+  if (M <= 16) {
+    // decode on the REFERENCE layout: 16 x 16 tiles, K over the 8 waves (N / 16 workgroups).  HBM-cold, graph replay, us, this kernel / the
+    // LDS-transposing decode kernels (gemm_skinny.hip, gemm_decode.hip) -- profiles/r03_decode_reference_layout_regtile.txt: N = K = 4096
+    // (BASELINE config[1]) M = 1 5.55 / 6.74, M = 16 6.75 / 8.30; 10752 x 3648 9.6 / 11.1; 1024 x 4160 5.1 / 6.0; 14336 x 4160 12.3 / 12.5; it
+    // loses where a wave has many short rounds or a very long K at M <= 8: 37888 x 3648 M = 1 25.7 / 20.7, 3584 x 19008 M = 1 14.6 / 13.5
+    if (M > 8 || (N <= 16384 && K <= 8448)) return 9;
     return 0;
   }
   if ((double)M * (double)N * (double)K > 1.6e10) return 0;
@@ -405,6 +415,9 @@ int gemm_regtile(const GemmArgs& a, int cfg, hipStream_t stream) {
     case 6: return launch_regtile<4, 2, 1, 1, 8>(a, stream);
     case 7: return launch_regtile<2, 2, 1, 1, 8>(a, stream);
     case 8: return launch_regtile<4, 4, 2, 1, 4>(a, stream);
+    case 9: return launch_regtile<1, 1, 1, 1, 8>(a, stream);
+    case 10: return launch_regtile<1, 2, 1, 1, 8>(a, stream);
+    case 11: return launch_regtile<1, 4, 1, 1, 8>(a, stream);
     default: return fail(ARCQ_ERR_UNSUPPORTED, "arcq_gemm_nvfp4 (regtile): unknown configuration %d", cfg);
   }
 }

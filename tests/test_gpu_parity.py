@@ -201,6 +201,11 @@ GEMM_CASES = [
     (4, 5120, 64, 0, O.G16),          # K = 64: a single scale atom, on each of the three kernels
     (3, 200, 64, 0, O.G16),
     (40, 256, 64, 0, O.G16),
+    # M <= 16 now runs gemm_regtile.hip's 16 x 16 tiles by default (the cases above); the LDS-transposing decode kernels keep the shapes
+    # where they measured faster -- M <= 8 with K > 8448 or N > 16384:
+    (4, 384, 8512, 64, O.G16),        # 16-row decode kernel (gemm_skinny.hip), long K
+    (2, 5120, 8512, 0, O.G16),        # 32-row decode kernel (gemm_decode.hip), long K
+    (8, 16400, 256, 64, O.G16),       # 32-row decode kernel, N > 16384, ragged N
     # gemm_regtile.hip (16 < M, one round of <= 256 and >= 96 workgroups of its smallest fitting tile): every configuration its heuristic
     # picks, K tails of 0 / 1 / 2 / 3 atoms
     (24, 3104, 256, 64, O.G16),       # 32 x 32 tiles (2 x 2 MFMA tiles per wave, ring of 4 steps), one quad-step + 1 tail atom, 24 live token rows
@@ -611,12 +616,13 @@ def test_silu_mul_gemm_epilogue_equals_the_unfused_steps():
 
 
 def test_gemm_epilogue_operands_on_every_kernel():
-    """bias + residual + device scale through the 16-row decode kernel, the 32-row decode kernel, the register-tiled kernel
+    """bias + residual + device scale through the register-tiled kernel's decode tiles (M <= 16), the 16-row and the 32-row decode
+    kernel (K > 8448), the register-tiled kernel
     (gemm_regtile.hip: 64 x 64, 32 x 32, 64 x 32, 64 x 64 and 128 x 64 tiles), the split-K tile path and the 128 x 128 tile: the fused epilogue equals the separate torch ops on the plain result, and doubling
     alpha doubles the fp32 output exactly (linearity in the per-tensor scale; a power of two commutes with every
     rounding)."""
     ag = _agemm()
-    for (M, N, KQ) in [(4, 384, 512), (4, 5120, 512), (40, 512, 1984), (300, 2048, 256), (60, 3200, 512), (128, 2100, 256), (250, 2500, 320), (300, 4100, 256), (1100, 256, 256)]:
+    for (M, N, KQ) in [(4, 384, 512), (4, 5120, 512), (4, 384, 8512), (4, 5120, 8512), (40, 512, 1984), (300, 2048, 256), (60, 3200, 512), (128, 2100, 256), (250, 2500, 320), (300, 4100, 256), (1100, 256, 256)]:
         qx, sfx, qw, sfw, alpha = _make_operands(M, N, KQ, 64, O.G16, 3 * M + N)
         A, B = torch.from_numpy(qx).to(DEV), torch.from_numpy(qw).to(DEV)
         SFA, SFB = torch.from_numpy(sfx).to(DEV), torch.from_numpy(sfw).to(DEV)
