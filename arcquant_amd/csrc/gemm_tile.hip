@@ -348,13 +348,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
   const float alpha = p.alpha_host * (p.alpha_dev ? *p.alpha_dev : 1.0f);
   const bool vec_ok = (p.N & 3) == 0;
   uint32_t act_max = 0;                       // kEpiSiluMul: max |act| of this thread, as bf16 magnitude bits
-  auto store4 = [&](int m, int n, float d0, float d1, float d2, float d3) {
+  // `pre`: the four bias / residual values of (m, n .. n + 3) already fetched with ONE 8-byte load each (N % 4 == 0), two bf16 per dword;
+  // otherwise they are read element by element (ragged N).  Same operations in the same order either way.
+  auto store4 = [&](int m, int n, float d0, float d1, float d2, float d3, bool pre, uint2 bias2, uint2 res2) __attribute__((always_inline)) {
     if (m >= p.M || n >= p.N) return;
+    const uint32_t bw[2] = {bias2.x, bias2.y}, rw[2] = {res2.x, res2.y};
+    auto bias_at = [&](int r) { return bf16_bits_to_f32(pre ? (bw[r >> 1] >> (16 * (r & 1))) & 0xffffu : (uint32_t)p.bias[n + r]); };
     if (kEpi == kEpiSiluMul) {                // columns n..n+3 = (gate_j, up_j, gate_j+1, up_j+1), j = n / 2; N % 4 == 0
       uint32_t y[4] = {f32_to_bf16_bits(alpha * d0), f32_to_bf16_bits(alpha * d1), f32_to_bf16_bits(alpha * d2), f32_to_bf16_bits(alpha * d3)};
       if (p.bias) {                             // `y = matmul(...); y = y + bias` of the separate GEMM, in bf16 (qLinearLayer.py:74-76)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = f32_to_bf16_bits(bf16_bits_to_f32(y[e]) + bf16_bits_to_f32(p.bias[n + e]));
+        for (int e = 0; e < 4; ++e) y[e] = f32_to_bf16_bits(bf16_bits_to_f32(y[e]) + bias_at(e));
       }
       const uint32_t a0 = silu_mul_bf16(y[0], y[1]);
       const uint32_t a1 = silu_mul_bf16(y[2], y[3]);
@@ -370,13 +374,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
     if (p.bias) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (n + r < p.N) d[r] = (p.out_dtype == ARCQ_OUT_F32 ? d[r] : bf16_bits_to_f32(f32_to_bf16_bits(d[r]))) + bf16_bits_to_f32(p.bias[n + r]);
+        if (pre || n + r < p.N) d[r] = (p.out_dtype == ARCQ_OUT_F32 ? d[r] : bf16_bits_to_f32(f32_to_bf16_bits(d[r]))) + bias_at(r);
     }
     if (p.residual) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (n + r < p.N) {
-          const float res = bf16_bits_to_f32(p.residual[(size_t)m * p.N + n + r]);
+        if (pre || n + r < p.N) {
+          const float res = bf16_bits_to_f32(pre ? (rw[r >> 1] >> (16 * (r & 1))) & 0xffffu : (uint32_t)p.residual[(size_t)m * p.N + n + r]);
           d[r] = (p.out_dtype == ARCQ_OUT_F32 ? d[r] : bf16_bits_to_f32(f32_to_bf16_bits(d[r]))) + res;
         }
     }
@@ -390,22 +394,53 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
       else for (int r = 0; r < 4; ++r) if (n + r < p.N) o[r] = (uint16_t)f32_to_bf16_bits(d[r]);
     }
   };
+  if constexpr (kMfma32) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      if constexpr (kMfma32) {
+      for (int j = 0; j < TN; ++j) {
         const int m = m0 + wr * WM + i * 32 + (lane & 31);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int n = n0 + wc * WN + j * 32 + 8 * g + 4 * (lane >> 5);
-          store4(m, n, acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+          store4(m, n, acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3], false, make_uint2(0, 0), make_uint2(0, 0));
         }
-      } else {
-        const int m = m0 + wr * WM + i * 16 + (lane & 15);
-        const int n = n0 + wc * WN + j * 16 + 4 * (lane >> 4);
-        store4(m, n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
       }
+  } else {
+    // Epilogue operands, fetched AHEAD of their use: a lane's TN bias quads once (they do not depend on the row), the residual quads of
+    // row tile i + 1 while row tile i is finished and stored.  (Element-wise loads inside store4, each awaited before the next, cost the
+    // model's prefill GEMMs + 19 % with a bias, + 32 % with a residual: tools/tile_epilogue_cost.py.)
+    const bool pre = vec_ok && p.splits <= 1;
+    const int nb = n0 + wc * WN + 4 * (lane >> 4), mb = m0 + wr * WM + (lane & 15);
+    if (pre) {                                 // (two copies of the store loops: `pre` as a constant inside each keeps store4 free of branches on it)
+      uint2 bias_v[TN], res_cur[TN], res_nxt[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bias_v[j] = res_cur[j] = res_nxt[j] = make_uint2(0, 0);
+        if (p.bias && nb + j * 16 < p.N) bias_v[j] = *reinterpret_cast<const uint2*>(p.bias + nb + j * 16);
+      }
+      auto res_load = [&](int i, uint2 (&r)[TN]) {
+        if (!p.residual) return;
+        const int m = mb + i * 16;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          if (m < p.M && nb + j * 16 < p.N) r[j] = *reinterpret_cast<const uint2*>(p.residual + (size_t)m * p.N + nb + j * 16);
+      };
+      res_load(0, res_cur);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (i + 1 < TM) res_load(i + 1, res_nxt);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) store4(mb + i * 16, nb + j * 16, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3], true, bias_v[j], res_cur[j]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) res_cur[j] = res_nxt[j];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          store4(mb + i * 16, nb + j * 16, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3], false, make_uint2(0, 0), make_uint2(0, 0));
     }
   }
   if (kEpi == kEpiSiluMul) {
