@@ -410,7 +410,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tile_kernel(TilePa
     // Epilogue operands, fetched AHEAD of their use: a lane's TN bias quads once (they do not depend on the row), the residual quads of
     // row tile i + 1 while row tile i is finished and stored.  (Element-wise loads inside store4, each awaited before the next, cost the
     // model's prefill GEMMs + 19 % with a bias, + 32 % with a residual: tools/tile_epilogue_cost.py.)
-    const bool pre = vec_ok && p.splits <= 1;
+    const bool pre = vec_ok && p.splits <= 1 && ((reinterpret_cast<uintptr_t>(p.bias) | reinterpret_cast<uintptr_t>(p.residual)) & 7) == 0;   // (a sliced view may be misaligned)
     const int nb = n0 + wc * WN + 4 * (lane >> 4), mb = m0 + wr * WM + (lane & 15);
     if (pre) {                                 // (two copies of the store loops: `pre` as a constant inside each keeps store4 free of branches on it)
       uint2 bias_v[TN], res_cur[TN], res_nxt[TN];

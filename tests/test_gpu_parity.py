@@ -637,6 +637,27 @@ def test_gemm_epilogue_operands_on_every_kernel():
         assert torch.equal(got, want), (M, N, KQ)
 
 
+def test_gemm_epilogue_operands_as_misaligned_views():
+    """bias / residual that are 2-byte-offset views (not 8-byte aligned): the kernels fall back from their 8-byte operand loads to
+    element loads and give the same bits (tile GEMM 256 x 256 and 128 x 256, register-tiled kernel at M = 4 and M = 200)."""
+    ag = _agemm()
+    for (M, N, KQ) in [(4, 384, 512), (200, 2500, 320), (300, 256, 256), (1100, 256, 256)]:
+        qx, sfx, qw, sfw, alpha = _make_operands(M, N, KQ, 64, O.G16, 5 * M + N)
+        A, B = torch.from_numpy(qx).to(DEV), torch.from_numpy(qw).to(DEV)
+        SFA, SFB = torch.from_numpy(sfx).to(DEV), torch.from_numpy(sfw).to(DEV)
+        g = torch.Generator().manual_seed(N + 1)
+        bias = torch.randn(N, generator=g).to(torch.bfloat16).to(DEV)
+        res = torch.randn(M, N, generator=g).to(torch.bfloat16).to(DEV)
+        want = ag.matmul(A, B, SFA, SFB, alpha, bias=bias, residual=res)
+        bias_off = torch.empty(N + 1, dtype=torch.bfloat16, device=DEV)[1:]
+        res_off = torch.empty(M * N + 1, dtype=torch.bfloat16, device=DEV)[1:].view(M, N)
+        bias_off.copy_(bias)
+        res_off.copy_(res)
+        assert bias_off.data_ptr() % 8 == 2 and res_off.data_ptr() % 8 == 2
+        got = ag.matmul(A, B, SFA, SFB, alpha, bias=bias_off, residual=res_off)
+        assert torch.equal(got, want), (M, N, KQ)
+
+
 @pytest.mark.parametrize("M,N", [(1, 1), (2, 16), (16, 17), (33, 1)])
 def test_gemm_tiny_output_shapes(M, N):
     ag = _agemm()
