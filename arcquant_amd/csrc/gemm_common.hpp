@@ -141,6 +141,15 @@ __device__ __forceinline__ void finish4_pre(const P& p, float alpha, int m, int 
 
 template <typename Idx, typename P>
 __device__ __forceinline__ void finish4(const P& p, float alpha, int m, int n, const float (&acc)[4]) {
+  // the common case -- N % 4 == 0, operands 8-byte aligned: ONE 8-byte load per operand instead of four element loads that hipcc awaits
+  // one by one (on the tile GEMM's prefill shapes that cost + 19 % with a bias and + 32 % with a residual)
+  if ((p.N & 3) == 0 && (p.bias || p.residual) && ((reinterpret_cast<uintptr_t>(p.bias) | reinterpret_cast<uintptr_t>(p.residual)) & 7) == 0) {
+    uint2 b2 = make_uint2(0, 0), r2 = make_uint2(0, 0);
+    if (p.bias) b2 = *reinterpret_cast<const uint2*>(p.bias + n);
+    if (p.residual) r2 = *reinterpret_cast<const uint2*>(p.residual + ((Idx)m * (Idx)p.N + (Idx)n));
+    finish4_pre<Idx>(p, alpha, m, n, acc, b2, r2);
+    return;
+  }
   float d[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {

@@ -294,20 +294,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KSPLIT * 64) void gemm_regtile_ke
   ARCQ_RT_STAMP(3);
   // ---- the K splits meet in LDS: [wave][tile][lane] float4; split ks then finishes tiles ks, ks + KSPLIT, ... of its (wm, wn) block
   const float alpha = p.alpha_host * (p.alpha_dev ? *p.alpha_dev : 1.0f);
-  // bias / residual of (m, n .. n + 3) as one 8-byte load each (any torch allocation is aligned; a sliced view may not be)
-  const bool quad_ok = (p.N & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.bias) | reinterpret_cast<uintptr_t>(p.residual)) & 7) == 0;
   auto finish_tile = [&](int i, int t, const f32x4& s) __attribute__((always_inline)) {
     const int m = m0 + 16 * i + r, n = n0 + 16 * t + 4 * c;
     if (m < p.M && n < p.N) {
       const float d[4] = {s[0], s[1], s[2], s[3]};
-      if (quad_ok) {
-        uint2 b2 = make_uint2(0, 0), r2 = make_uint2(0, 0);
-        if (p.bias) b2 = *reinterpret_cast<const uint2*>(p.bias + n);
-        if (p.residual) r2 = *reinterpret_cast<const uint2*>(p.residual + (size_t)m * p.N + n);
-        finish4_pre<size_t>(p, alpha, m, n, d, b2, r2);
-      } else {
-        finish4<size_t>(p, alpha, m, n, d);
-      }
+      finish4<size_t>(p, alpha, m, n, d);                   // (8-byte operand loads when N % 4 == 0: gemm_common.hpp)
     }
   };
   if constexpr (KSPLIT == 1) {
