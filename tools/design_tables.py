@@ -42,13 +42,14 @@ for k, v in sw.items():
     sweep += (f"| {k[1:]} | {v.get('reference_layout_us', v['us']):.2f} | {('%.2f' % v['repacked_us']) if 'repacked_us' in v else ''} | {v['TFLOPs']:.1f} | "
               f"{v['GBps']:.0f} | {v['bound']} | {v['frac_of_bounding_roof']:.3f} |\n")
 pg = e["prefill_gemms"]
-pre = "| GEMM (M = 4096, KE = 64) | µs | TFLOP/s | of the fp16 roof |\n|---|---|---|---|\n"
+pre = "| GEMM (M = 4096, KE = 64) | µs | TFLOP/s | of the fp16 roof | µs with the model's bias / residual |\n|---|---|---|---|---|\n"
 for k, v in pg.items():
     if isinstance(v, dict):
-        pre += f"| {k} | {v['us']:.1f} | {v['TFLOPs']:.0f} | {v['frac']:.3f} |\n"
+        tail = f"{v['us_as_in_model']:.1f} ({v.get('epilogue_operand', 'all four')})" if "us_as_in_model" in v else ""
+        pre += f"| {k} | {v['us']:.1f} | {v['TFLOPs']:.0f} | {v['frac']:.3f} | {tail} |\n"
 res = f"""**Results of the committed run** (`profiles/r03_bench_full.json`, one MI355X; the same command under `rocprofv3 --kernel-trace --stats`:
-`profiles/r03_bench_kernel_trace_summary.txt`, `r03_bench_kernel_stats.csv`). Box to box the sustained headline ranged 1362–1379 TFLOP/s this
-round (`roofline.frac` 0.546–0.553), the library GEMM beside it 1426–1447 on randn operands:
+`profiles/r03_bench_kernel_trace_summary.txt`, `r03_bench_kernel_stats.csv`). Box to box the sustained headline ranged 1342–1379 TFLOP/s this
+round (`roofline.frac` 0.538–0.553), the library GEMM beside it 1426–1447 on randn operands:
 
 | what | value |
 |---|---|
