@@ -67,7 +67,11 @@ def launch_ranks(n: int, cmd, env_extra=None, need_json: bool = True, timeout_s:
     out0.seek(0)
     text = out0.read()
     out0.close()
-    sys.stdout.write(text)
+    if need_json:         # the contract is ONE JSON line on standard output: whatever else rank 0 (or a library under it) printed goes to stderr
+        for line in text.splitlines(keepends=True):
+            (sys.stdout if line.startswith("{") else sys.stderr).write(line)
+    else:
+        sys.stdout.write(text)
     sys.stdout.flush()
     if rc == 0 and need_json and not any(line.startswith("{") for line in text.splitlines()):
         sys.stderr.write("launch_ranks: rank 0 printed no JSON line\n")

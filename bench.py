@@ -595,6 +595,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
+    # The contract is ONE JSON line on standard output.  Libraries print there too (gloo: "[Gloo] Rank 0 is connected to ..."), from C,
+    # past sys.stdout: keep the real descriptor aside, point fd 1 at stderr for the whole run, and write the line to the kept one.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     # Rehearsal switches (not used by the driver): ARCQ_BENCH_ONE_DEVICE=1 maps every rank to cuda:0 and
     # ARCQ_BENCH_BACKEND=gloo replaces RCCL, so the N > 1 code path can be exercised on a one-GPU box.
     one_device = os.environ.get("ARCQ_BENCH_ONE_DEVICE") == "1"
@@ -745,7 +750,7 @@ def main():
                                 "+ all-gather); us = max over ranks, HIP events around GEMM + collective")
             result["extra"] = {"strong_scaling": strong_x}
     if rank == 0:
-        print(json.dumps(result))
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -34,8 +34,8 @@ def _start(cmd, tmp_path):
 def test_bench_gpus_2_starts_its_own_ranks_and_prints_one_json_line(tmp_path):
     r = _start([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--prewarm-ms", "0", "--no-cpu"], tmp_path)
     assert r["rc"] == 0, r["stderr"]
-    lines = [l for l in r["stdout"].splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r["stdout"]
+    lines = r["stdout"].splitlines()                          # exactly ONE line, the JSON: library chatter (gloo prints to fd 1) goes to stderr
+    assert len(lines) == 1 and lines[0].startswith("{"), r["stdout"]
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["steps"] == 3 and res["value"] > 0
     assert res["roofline"]["bound"] == "mfma" and res["roofline"]["achieved"] > 0

@@ -2,9 +2,11 @@
 # passes of the tile GEMM (traffic) and of the decode GEMMs, in-kernel stamps of the stream kernel, decode-batch sweep, the
 # multi-GPU paths rehearsed on one device.  Usage (gpurun): bash tools/scripts/prof_r03.sh <tag>
 tag=${1:-r03z}
+part=${2:-all}     # 1 = bench + profiles + tile PMC, 2 = decode PMC + stamps + sweeps + multi-GPU rehearsal (each fits one 20-minute gpurun call)
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
+if [ $part != 2 ]; then
 python bench.py > gpurun_out/${tag}_bench_full.json 2> gpurun_out/${tag}_bench_full.err || exit 1
 echo "bench done"
 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_prof -o out --output-format csv -- python3 bench.py --no-extra --no-cpu > gpurun_out/${tag}_bench_profiled_stdout.json 2> gpurun_out/${tag}_prof.log || exit 1
@@ -26,6 +28,8 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_AN
   rm -rf gpurun_out/${tag}pmc_$g
 done
 echo "pmc tile done"
+fi
+if [ $part = 1 ]; then ls gpurun_out/${tag}_*; exit 0; fi
 # PMC: the decode GEMMs on the Qwen2.5-7B gate|up shape
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVES SQ_LDS_BANK_CONFLICT"; do
   g=$(echo $grp | cut -d' ' -f1)

@@ -23,3 +23,15 @@ for (m, n, kq) in [(4096, 10752, 3584), (4096, 3584, 3584), (4096, 3584, 18944),
     print(json.dumps(rec), flush=True)
     del q, res, out
     torch.cuda.empty_cache()
+# the gate|up GEMM with the SiLU * up epilogue (interleaved gate / up rows), without and with its bias; and the headline shape
+q = make_problem(4096, 37888, 3584, 64, dev)
+bias = torch.randn(37888, generator=torch.Generator().manual_seed(2)).to(torch.bfloat16).to(dev)
+rec = {"shape": [4096, 37888, 3584], "epilogue": "silu*up"}
+for name, kw in (("plain", {}), ("bias", {"bias": bias})):
+    rec[name] = round(time_events_steady(lambda: agemm.matmul_silu_mul(q["qx"], q["qw"], q["sfx"], q["sfw"], q["alpha"], **kw), 20, 30.0), 2)
+print(json.dumps(rec), flush=True)
+del q
+torch.cuda.empty_cache()
+q = make_problem(4096, 4096, 4096, 64, dev)
+out = torch.empty((4096, 4096), dtype=torch.bfloat16, device=dev)
+print(json.dumps({"shape": [4096, 4096, 4096], "plain": round(time_events_steady(lambda: agemm.matmul(q["qx"], q["qw"], q["sfx"], q["sfw"], q["alpha"], out=out), 100, 60.0), 2)}), flush=True)
