@@ -337,10 +337,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KSPLIT * 64) void gemm_regtile_ke
 //   1 = 4x4 1x1x8 (64 x 64 per workgroup)   2 = 4x4 1x2x4 (64 x 128)   3 = 4x4 2x2x2 (128 x 128)   4 = 4x4 2x4x1 (128 x 256)
 //   5 = 2x4 1x1x8 (32 x 64)                 6 = 4x2 1x1x8 (64 x 32)     7 = 2x2 1x1x8 (32 x 32)     8 = 4x4 2x1x4 (128 x 64)
 //   9 = 1x1 1x1x8 (16 x 16)                 10 = 1x2 1x1x8 (16 x 32)    11 = 1x4 1x1x8 (16 x 64)    (decode batches on the reference layout)
+//   12 = 2x1 1x1x8 (32 x 16)                13 = 4x1 1x1x8 (64 x 16)
 struct RegCfg { int id, bm, bn, ksplit, tm, tn; };
 static constexpr RegCfg kRegCfgs[] = {{1, 64, 64, 8, 4, 4}, {2, 64, 128, 4, 4, 4}, {3, 128, 128, 2, 4, 4}, {4, 128, 256, 1, 4, 4},
                                       {5, 32, 64, 8, 2, 4}, {6, 64, 32, 8, 4, 2},  {7, 32, 32, 8, 2, 2},   {8, 128, 64, 4, 4, 4},
-                                      {9, 16, 16, 8, 1, 1}, {10, 16, 32, 8, 1, 2}, {11, 16, 64, 8, 1, 4}};
+                                      {9, 16, 16, 8, 1, 1}, {10, 16, 32, 8, 1, 2}, {11, 16, 64, 8, 1, 4},
+                                      {12, 32, 16, 8, 2, 1}, {13, 64, 16, 8, 4, 1}};
 
 static int regtile_override() {              // ARCQ_REGTILE_CFG: 0 = by shape, -1 = never (the tiled kernel), n = forced configuration
   static const int v = getenv("ARCQ_REGTILE_CFG") ? atoi(getenv("ARCQ_REGTILE_CFG")) : 0;
@@ -373,7 +375,7 @@ static int launch_regtile(const GemmArgs& a, hipStream_t stream) {
 // 0 = the tiled kernel serves this shape, else the configuration: the SMALLEST tile whose grid is one round of the chip (<= 256 workgroups;
 // >= 96, or the tiled kernel's split-K fills the chip better), up to ~1.6 * 10^10 of M N K, where the tiled kernel's one dequantisation per
 // workgroup starts to win.  Measured (tools/midm_tile_sweep.py, profiles/r03_midm_regtile_sweep.jsonl; graph replay, us, this kernel / the tiled
-// kernel): N = K = 4096: M = 32 9.0 / 15.7, 64 9.1 / 20.6, 128 11.3 / 25.8, 256 16.8 / 27.2, 512 27.5 / 32.6, 1024 46.8 / 46.5;
+// kernel): N = K = 4096: M = 32 7.7 (32 x 16 tiles; 32 x 32: 9.5) / 15.7, 64 9.1 / 20.6, 128 11.3 / 25.8, 256 16.8 / 27.2, 512 27.5 / 32.6, 1024 46.8 / 46.5;
 // N = 10752, K = 3584: M = 32 11.4 / 20.1, 64 15.4 / 25.9, 128 25.9 / 28.7, 256 40.8 / 43.9, 512 75.6 / 65.0; N = 3584, K = 18944: M = 64 25.2 /
 // 34.1, 128 35.8 / 46.2, 256 54.3 / 59.6, 512 94.6 / 92.4, 1024 172 / 156.
 int gemm_regtile_cfg(int64_t M, int64_t N, int64_t K, int epilogue) {
@@ -395,7 +397,7 @@ int gemm_regtile_cfg(int64_t M, int64_t N, int64_t K, int epilogue) {
     return 0;
   }
   if ((double)M * (double)N * (double)K > 1.6e10) return 0;
-  static const int order[] = {7, 6, 5, 1, 8, 2, 3};           // by tile area, token-narrow before row-narrow
+  static const int order[] = {12, 7, 6, 5, 1, 8, 2, 3};       // by tile area, token-narrow before row-narrow
   for (int id : order)
     for (const RegCfg& c : kRegCfgs) {
       if (c.id != id || (c.bm > 32 && c.bm >= 2 * M)) continue;       // a tile twice as tall as the batch multiplies padding
@@ -418,6 +420,8 @@ int gemm_regtile(const GemmArgs& a, int cfg, hipStream_t stream) {
     case 9: return launch_regtile<1, 1, 1, 1, 8>(a, stream);
     case 10: return launch_regtile<1, 2, 1, 1, 8>(a, stream);
     case 11: return launch_regtile<1, 4, 1, 1, 8>(a, stream);
+    case 12: return launch_regtile<2, 1, 1, 1, 8>(a, stream);
+    case 13: return launch_regtile<4, 1, 1, 1, 8>(a, stream);
     default: return fail(ARCQ_ERR_UNSUPPORTED, "arcq_gemm_nvfp4 (regtile): unknown configuration %d", cfg);
   }
 }

@@ -208,8 +208,8 @@ GEMM_CASES = [
     (8, 16400, 256, 64, O.G16),       # 32-row decode kernel, N > 16384, ragged N
     # gemm_regtile.hip (16 < M, one round of <= 256 and >= 96 workgroups of its smallest fitting tile): every configuration its heuristic
     # picks, K tails of 0 / 1 / 2 / 3 atoms
-    (24, 3104, 256, 64, O.G16),       # 32 x 32 tiles (2 x 2 MFMA tiles per wave, ring of 4 steps), one quad-step + 1 tail atom, 24 live token rows
-    (64, 1600, 2112, 64, O.G16),      # ... 8 quad-steps over 8 waves + 2 tail atoms
+    (24, 3104, 256, 64, O.G16),       # 32 x 16 tiles (2 x 1 MFMA tiles per wave, ring of 4 steps), one quad-step + 1 tail atom, 24 live token rows
+    (64, 2112, 2112, 64, O.G16),      # 32 x 32 tiles (the 32 x 16 grid would exceed one round), 8 quad-steps over 8 waves + 2 tail atoms
     (32, 8200, 256, 64, O.G16),       # 32 x 64 tiles (the 32 x 32 grid would exceed one round)
     (100, 2110, 320, 64, O.G32),      # 64 x 32 tiles, ragged M and N (N % 16 != 0, N % 4 != 0: scalar stores), 2 tail atoms
     (256, 2048, 1024, 0, O.G16),      # ... K % 256 == 0: no tail, 4 quad-steps over 8 waves (some waves idle)

@@ -31,4 +31,6 @@ for name, kq in (("hidden", 3584), ("intermediate", 18944)):
     slots = torch.full((2368,), 0x4000, dtype=torch.int32, device=dev)
     t = time_events_steady(lambda: agemm.reorder_quantize_x_dynamic(x, idx, KE, absmax_slots=slots), 30, 20.0)
     rec["reorder_quantize_x_dynamic_us (abs-max words given)"] = round(t, 2); rec["dynamic_TBps"] = round(byt / t / 1e6, 2)
+    t = time_events_steady(lambda: agemm.reorder_quantize_x_dynamic(x, None, KE, absmax_slots=slots), 30, 20.0)
+    rec["... input already in reordered channel order (no gather)"] = round(t, 2)
     print(json.dumps(rec), flush=True)
