@@ -404,6 +404,9 @@ int gemm_regtile_cfg(int64_t M, int64_t N, int64_t K, int epilogue) {
       const int64_t wgs = ((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
       if (wgs <= 256) return wgs >= 96 ? id : 0;
     }
+  // no tile covers the problem in one round (very wide weights): up to three rounds of 32 x 64 / 64 x 64 tiles still beat the tiled kernel's
+  // split-K for decode batches (37888 x 3648, graph replay: M = 32 34.5 against 39.6 us, M = 64 48.0 against 52.3; from M = 128 it loses)
+  if (M <= 64 && ((N + 63) / 64) <= 768) return M <= 32 ? 5 : 1;
   return 0;
 }
 
