@@ -217,6 +217,8 @@ GEMM_CASES = [
     (300, 4100, 576, 64, O.G16),      # 128 x 64 tiles (waves 2 x 1 x 4), 2 tail atoms
     (192, 10000, 256, 64, O.G16),     # 64 x 128 tiles (waves 1 x 2 x 4)
     (256, 10752, 256, 64, O.G16),     # 128 x 128 tiles (waves 2 x 2 x 2)
+    (20, 16448, 256, 64, O.G16),      # very wide weight, no one-round tile: 32 x 64 tiles over two rounds
+    (40, 16448, 256, 0, O.G16),       # ... 64 x 64 tiles
 ]
 
 
