@@ -3,26 +3,29 @@
 //
 // Why not the LDS-tiled kernel (gemm_tile.hip) here: with few tokens the grid of 128 x 128 / 256 x 256 tiles does not fill 256 CUs, so
 // that kernel splits K over workgroups (fp32 partial planes + a finish launch: 16.8 MB written and re-read at M = 256, N = 4096) and
-// still spends its time in a K loop of one barrier per 64 K elements with the global loads only two steps ahead -- every step costs a
-// load latency, whatever the tile (measured, profiles/r03_midm_tile_sweep.jsonl: M = 256, N = K = 4096 takes 26-34 us under every
-// one of 17 tile / split configurations; the arithmetic is 3.4 us).  Here (reference: the one CUTLASS instantiation of
-// kernels/src/nvfp4.cu:48-74 serves every M):
-//   * a wave owns a 64-token x 64-row output tile (4 x 4 MFMA 16x16x32 tiles) and reads its operand fragments STRAIGHT from the
-//     reference layout into the MFMA operand registers: lane (r, c) of fragment i takes the 32 packed bytes of row 16 i + r that
-//     hold scale-factor atom 4 s + c of quad-step s (64 K elements = 4 groups, their 4 scale bytes are ONE aligned dword of the
-//     swizzled layout), i.e. the four lane groups of a fragment cover one full 128-byte line per row and quad-step.  The K index a
-//     lane feeds into MFMA slot (c, j) is a fixed permutation of the true one, the SAME for both operands, so every product meets its
-//     partner (the contraction is a sum over K: order inside the fp32 chain differs from the tiled kernel, the set of products does not);
-//   * no LDS and no barrier in the K loop: the next quad-step's loads are issued while this one is multiplied (256 K per step and
-//     operand = 2 x 16 bytes + 1 scale dword per lane and fragment);
-//   * the eight waves of a workgroup split K (KSPLIT = 8: one 64 x 64 tile per workgroup, 256 workgroups at M = 256, N = 4096), or tile a
-//     larger block with less K splitting (2 x 4 x 1 ... 1 x 1 x 8); the partial tiles meet in LDS once, at the end, summed in a fixed
-//     order (deterministic), and the epilogue (alpha, bias, residual, bf16 rounding: gemm_common.hpp finish4) is spread over the waves;
+// runs a K loop of one barrier per 64 K elements on tiles too small to cover it (measured, profiles/r03_midm_tile_sweep.jsonl:
+// M = 256, N = K = 4096 takes 26-34 us under every one of 17 tile / split configurations; the arithmetic is 3.4 us).  And the
+// LDS-transposing decode kernels (gemm_skinny.hip / gemm_decode.hip) spend ~92 instructions per 16 bytes of weights on their transpose.
+// Here (reference: the one CUTLASS instantiation of kernels/src/nvfp4.cu:48-74 serves every M):
+//   * a wave owns a (16 TM) token x (16 TN) row output tile -- 64 x 64 (4 x 4 MFMA 16x16x32 tiles) down to 16 x 16 for decode -- and
+//     reads its operand fragments STRAIGHT from the reference layout into the MFMA operand registers: lane (r, c) of fragment i takes
+//     the 32 packed bytes of row 16 i + r that hold scale-factor atom 4 s + c of quad-step s (64 K elements = 4 groups, their 4 scale
+//     bytes are ONE aligned dword of the swizzled layout), i.e. the four lane groups of a fragment cover one full 128-byte line per
+//     row and quad-step.  The K index a lane feeds into MFMA slot (c, j) is a fixed permutation of the true one, the SAME for both
+//     operands, so every product meets its partner (the contraction is a sum over K: order inside the fp32 chain differs from the
+//     tiled kernel, the set of products does not);
+//   * no LDS and no barrier in the K loop; operands are BUFFER loads (descriptor + 32-bit lane offset + scalar step offset) requested one
+//     step ahead (64 x 64 tiles, in halves rotating through three register sets) or up to three steps ahead (smaller tiles), every wait
+//     counted (see the loop);
+//   * the eight waves of a workgroup split K (KSPLIT = 8: one tile per workgroup -- 256 workgroups at M = 256, N = 4096 with 64 x 64,
+//     at M <= 16 with 16 x 16), or tile a larger block with less K splitting (2 x 4 x 1 ... 1 x 1 x 8); the partial tiles meet in LDS
+//     once, at the end, summed in a fixed order (deterministic), and the epilogue (alpha, bias, residual, bf16 rounding:
+//     gemm_common.hpp finish4) is spread over the waves;
 //   * a K tail that is not a multiple of 256 (KE = 64: one atom) runs as single-atom steps of a quarter of the MFMAs.
-// Bound: with K split inside the workgroup every operand byte enters a CU once per tile row / column: (64 WAVES_M + 64 WAVES_N) x K x
-// 9/16 bytes per workgroup from L2 / the Infinity Cache (66-73 GB/s per CU from L2, MI355X_MICROARCH.md "Indexed rows"), and the
-// dequantisation is per wave (64 + 64 rows per 64 x 64 tile: 2 x the tiled kernel's share per MFMA): the kernel is for grids the tiled
-// kernel cannot fill, not for prefill.
+// Bound: with K split inside the workgroup every operand byte enters a CU once per tile row / column: (BM + BN) x K x 9/16 bytes per
+// workgroup, delivered at 28-57 GB/s per CU for this access shape although 86-91 % of the requests hit L2 (profiles/r03_pmc_regtile.json),
+// and the dequantisation is per wave (64 + 64 rows per 64 x 64 tile: 2 x the tiled kernel's share per MFMA): the kernel is for grids
+// the tiled kernel cannot fill and for decode, not for prefill.  gemm_regtile_cfg below holds the measured crossovers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
